@@ -1,0 +1,157 @@
+"""TEST INFRASTRUCTURE ONLY.  ctypes front-end of the CPU oracle.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libiouaware_oracle.so')
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in
+            ('iouaware_oracle.c', 'iouaware_oracle_loss.c', 'ia_oracle_math.h', 'Makefile')]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.run(['make', '-C', _HERE, '-B', '_build/libiouaware_oracle.so'], check=True,
+                   stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.ia_o_count_sigmoid_nonmonotone.restype = C.c_longlong
+        _lib.ia_o_count_sigmoid_nonmonotone.argtypes = [C.c_float, C.c_float]
+        _lib.ia_o_focal_loss.restype = C.c_double
+        _lib.ia_o_smooth_l1.restype = C.c_double
+        _lib.ia_o_iou_bce.restype = C.c_double
+        _lib.ia_o_focal_loss_op_fwd.restype = None
+        _lib.ia_o_focal_loss_op_bwd.restype = None
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def vec(fn, x):
+    x = _f(x)
+    y = np.empty_like(x)
+    getattr(lib(), 'ia_o_vec_' + fn)(_fp(x), _fp(y), C.c_longlong(x.size))
+    return y
+
+
+def gen_base_anchors(base_size, scales, ratios):
+    scales = _f(scales)
+    ratios = _f(ratios)
+    out = np.empty((len(ratios) * len(scales), 4), np.float32)
+    lib().ia_o_gen_base_anchors(C.c_float(base_size), _fp(scales), len(scales), _fp(ratios),
+                                len(ratios), _fp(out))
+    return out
+
+
+def grid_anchors(base, H, W, stride):
+    base = _f(base)
+    out = np.empty((H * W * base.shape[0], 4), np.float32)
+    lib().ia_o_grid_anchors(_fp(base), base.shape[0], H, W, stride, _fp(out))
+    return out
+
+
+def delta2bbox(rois, deltas, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), max_shape=None):
+    rois, deltas = _f(rois), _f(deltas)
+    means, stds = _f(means), _f(stds)
+    out = np.empty_like(deltas)
+    has = 0 if max_shape is None else 1
+    h, w = (0, 0) if max_shape is None else (max_shape[0], max_shape[1])
+    lib().ia_o_delta2bbox(_fp(rois), _fp(deltas), rois.shape[0], _fp(means), _fp(stds), has,
+                          C.c_float(h), C.c_float(w), _fp(out))
+    return out
+
+
+def nms(dets, thr):
+    dets = _f(dets).reshape(-1, 5)
+    keep = np.empty(max(dets.shape[0], 1), np.int32)
+    m = lib().ia_o_nms(_fp(dets), dets.shape[0], C.c_float(thr), _ip(keep))
+    return keep[:m].astype(np.int64)
+
+
+def head_base_anchors(strides, octave_base_scale=4, scales_per_octave=3,
+                      ratios=(0.5, 1.0, 2.0)):
+    """anchor_scales of IoUawareRetinaHead.__init__ (iou_aware_retina_head.py:81-83)."""
+    octave = np.array([2 ** (i / scales_per_octave) for i in range(scales_per_octave)])
+    scales = (octave * octave_base_scale).astype(np.float32)   # torch.Tensor(scales) -> fp32
+    return np.stack([gen_base_anchors(s, scales, ratios) for s in strides])
+
+
+def get_bboxes_single(cls, reg, iou, strides, base_anchors, img_shape, scale_factor, rescale,
+                      nms_pre=1000, score_thr=0.05, iou_thr=0.5, max_per_img=100,
+                      means=(0, 0, 0, 0), stds=(1, 1, 1, 1), C_cls=80):
+    """cls/reg/iou: lists (one per level) of (ch,H,W) fp32 arrays of ONE image."""
+    L = len(cls)
+    cls = [_f(x) for x in cls]
+    reg = [_f(x) for x in reg]
+    iou = [_f(x) for x in iou]
+    A = iou[0].shape[0]
+    Hs = np.array([x.shape[1] for x in iou], np.int32)
+    Ws = np.array([x.shape[2] for x in iou], np.int32)
+    st = np.array(strides, np.int32)
+    Nl = [int(h) * int(w) * A for h, w in zip(Hs, Ws)]
+    kl = [min(nms_pre, n) if nms_pre > 0 else n for n in Nl]
+    N, R = sum(Nl), sum(kl)
+    base = _f(base_anchors)
+    sf = np.asarray(scale_factor, np.float32).reshape(-1)
+    sf = _f(np.repeat(sf, 4) if sf.size == 1 else sf)
+    means, stds = _f(means), _f(stds)
+    PP = _f32p * L
+    rowmax = np.empty(N, np.float32)
+    topk = np.empty(R, np.int32)
+    boxes = np.empty((R, 4), np.float32)
+    scores = np.empty((R, C_cls), np.float32)
+    kc = np.zeros(C_cls, np.int32)
+    kr = np.zeros((C_cls, R), np.int32)
+    mp = max(max_per_img, 0) if max_per_img >= 0 else R * C_cls
+    db = np.zeros((max(mp, 1), 5), np.float32)
+    dl = np.zeros(max(mp, 1), np.int32)
+    dr = np.zeros(max(mp, 1), np.int32)
+    Rout = C.c_int32(0)
+    fn = lib().ia_o_get_bboxes_single
+    fn.restype = C.c_int
+    nd = fn(L, PP(*[_fp(x) for x in cls]), PP(*[_fp(x) for x in reg]),
+            PP(*[_fp(x) for x in iou]), _ip(Hs), _ip(Ws), _ip(st), _fp(base), A, C_cls,
+            _fp(means), _fp(stds), C.c_float(img_shape[0]), C.c_float(img_shape[1]), _fp(sf),
+            int(bool(rescale)), int(nms_pre), C.c_float(score_thr), C.c_float(iou_thr),
+            int(max_per_img), _fp(rowmax), _ip(topk), _fp(boxes), _fp(scores), _ip(kc), _ip(kr),
+            _fp(db), _ip(dl), _ip(dr), C.byref(Rout))
+    assert Rout.value == R
+    lvl_off = np.cumsum([0] + Nl)
+    cand_off = np.cumsum([0] + kl)
+    return dict(rowmax=rowmax, topk_inds=topk, mlvl_bboxes=boxes, mlvl_scores=scores,
+                keep_count=kc, keep_rows=kr, det_bboxes=db[:nd].copy(),
+                det_labels=dl[:nd].astype(np.int64), det_rows=dr[:nd].copy(), num_det=nd,
+                level_off=lvl_off, cand_off=cand_off)
+
+
+def sigmoid_nonmonotone_count(lo, hi):
+    return int(lib().ia_o_count_sigmoid_nonmonotone(C.c_float(lo), C.c_float(hi)))
