@@ -1,0 +1,176 @@
+/*
+ * iouaware.h -- C-ABI of the MI355X-native (gfx950) IoU-aware RetinaNet
+ * post-conv hot path.  Shared library: libiouaware_hip.so (built by
+ * iou-aware-single-stage-object-detector_amd/csrc/build.py with hipcc).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / ATen types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host or the
+ *     comment says "host"; `stream` is a hipStream_t passed as void*.
+ *   - nothing is allocated: callers pass a workspace sized by the matching
+ *     *_workspace_bytes() query.  Calls are asynchronous on `stream`.
+ *   - return value: 0 = ok, negative = IA_E_* argument error, positive =
+ *     hipError_t of a failed launch.
+ *   - feature maps are NCHW, contiguous, dtype IA_F32 or IA_BF16; channel
+ *     a*C+c (cls), a*4+k (reg), a (iou) -- the reference head's output layout
+ *     (reference mmdet/models/anchor_heads/iou_aware_retina_head.py:171-219).
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the reference repository root).
+ */
+#ifndef IOUAWARE_H
+#define IOUAWARE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IA_MAX_LEVELS 8
+#define IA_MAX_ANCHORS 16
+#define IA_MAX_NMS_PRE 4096
+#define IA_MAX_CANDIDATES 8192     /* sum over levels of min(nms_pre, N_l) */
+#define IA_MAX_PER_IMG 1024
+
+#define IA_F32 0
+#define IA_BF16 1
+
+#define IA_E_ARG (-1)        /* invalid argument / unsupported size */
+#define IA_E_WORKSPACE (-2)  /* workspace too small */
+
+/* Static geometry of one head for one padded input size. */
+typedef struct ia_head_geom {
+    int32_t num_levels;                 /* L <= IA_MAX_LEVELS */
+    int32_t num_anchors;                /* A <= IA_MAX_ANCHORS */
+    int32_t num_classes;                /* C, sigmoid classes (80) */
+    int32_t nms_pre;                    /* <= 0: no per-level top-k */
+    int32_t H[IA_MAX_LEVELS];
+    int32_t W[IA_MAX_LEVELS];
+    int32_t stride[IA_MAX_LEVELS];
+    float base_anchors[IA_MAX_LEVELS][IA_MAX_ANCHORS][4];  /* AnchorGenerator.base_anchors */
+    float means[4], stds[4];            /* target_means / target_stds */
+} ia_head_geom;
+
+/* Per-level device pointers of the three head outputs, each (B, ch, H, W). */
+typedef struct ia_level_ptrs {
+    const void *cls[IA_MAX_LEVELS];
+    const void *reg[IA_MAX_LEVELS];
+    const void *iou[IA_MAX_LEVELS];
+} ia_level_ptrs;
+
+/* Derived sizes (host helper): N = anchors per image, R = candidates per image,
+ * Rs = R rounded up to 64 (row stride of class-major score / keep arrays).   */
+int ia_geom_sizes(const ia_head_geom *g, int32_t *N, int32_t *R, int32_t *Rs);
+
+const char *ia_version(void);
+
+/* ------------------------------------------------------------------ inference
+ * Stage entry points.  Together they replace IoUawareRetinaHead.get_bboxes /
+ * get_bboxes_single (iou_aware_retina_head.py:390-564) and multiclass_nms
+ * (mmdet/core/post_processing/bbox_nms.py:6-67).                             */
+
+/* iou_aware_retina_head.py:502-531,539: per anchor max over classes of
+ * sqrt(sigmoid(cls)) * sqrt(sigmoid(iou)).  rowmax: (B, N) fp32.             */
+int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                          float *rowmax, void *stream);
+
+/* iou_aware_retina_head.py:536-544 (topk per level, descending; ties broken by
+ * ascending anchor index).  cand_idx: (B, R) int32 level-local anchor index.  */
+int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_t *cand_idx,
+                   void *stream);
+
+/* iou_aware_retina_head.py:545-558 + mmdet/core/bbox/transforms.py:44-78
+ * (delta2bbox) + anchor_generator.py:53-70 (anchors regenerated, never read).
+ * img_hw: (B,2) fp32 (img_shape h,w); scale_factor: (B,4) fp32.
+ * boxes: (B,R,4) fp32; scores_t: (B,C,Rs) fp32 class-major fused scores.      */
+int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                     const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
+                     int rescale, float *boxes, float *scores_t, void *stream);
+
+/* bbox_nms.py:33-56 + mmdet/ops/nms/src/nms_cpu.cpp:4-59 (greedy, ">=",
+ * ascending kept indices), all (image, class) problems in one launch, then the
+ * per-image top max_per_img.  Outputs: dets (B,max_per_img,5) fp32, labels and
+ * rows (B,max_per_img) int32 (row = candidate row id), num (B) int32,
+ * keep_count (B,C) int32, keep_rows (B,C,Rs) int32 ascending.                 */
+int ia_multiclass_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
+                      float score_thr, float iou_thr, int max_per_img, float *dets,
+                      int32_t *labels, int32_t *rows, int32_t *num, int32_t *keep_count,
+                      int32_t *keep_rows, void *stream);
+
+/* Whole path in one call (what the Python head calls).                        */
+size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
+int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                  const float *img_hw, const float *scale_factor, int rescale, float score_thr,
+                  float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
+                  float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream);
+
+/* Workspace carve-up of ia_get_bboxes (host helper for stage-level tests):
+ * byte offsets of rowmax, cand_idx, boxes, scores_t, keep_count, keep_rows.   */
+int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[6]);
+
+/* mmdet.ops.nms.nms (mmdet/ops/nms/nms_wrapper.py:8-49 -> nms_cpu.nms /
+ * nms_cuda.nms): dets (n,5) fp32 on device, n <= IA_MAX_CANDIDATES.
+ * keep (n) int32 ascending input indices, count (1) int32.                    */
+int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *stream);
+
+/* ------------------------------------------------------------------- training
+ * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on
+ * the NCHW head outputs directly.  Each *_fwd ADDS one fp64 sum (the
+ * numerator the reference divides by avg_factor, losses.py:301-303,411,480)
+ * into *loss_sum (device, zeroed by the caller; one fp64 atomic per workgroup);
+ * each *_bwd writes gscale * d(sum)/d(input) with the input's NCHW shape.     */
+
+/* FocalLoss -> weighted_sigmoid_focal_loss -> py_sigmoid_focal_loss
+ * (mmdet/core/loss/losses.py:226-247,279-303) fused with expand_binary_labels
+ * (mmdet/core/anchor/anchor_target.py:247-254).  labels (B*N_l) int64,
+ * label_weights (B*N_l) fp32 in anchor order n = p*A + a.                     */
+int ia_focal_loss_fwd(const void *cls, int dtype, const int64_t *labels,
+                      const float *label_weights, int B, int A, int C, int HW, float gamma,
+                      float alpha, double *loss_sum, void *stream);
+int ia_focal_loss_bwd(const void *cls, int dtype, const int64_t *labels,
+                      const float *label_weights, int B, int A, int C, int HW, float gamma,
+                      float alpha, float gscale, float *grad_cls, void *stream);
+
+/* SmoothL1Loss -> weighted_smoothl1 (losses.py:385-411).  pred NCHW
+ * (B,A*4,H,W); target / weight (B,N_l,4) row-major.                           */
+int ia_smooth_l1_fwd(const void *pred, int dtype, const float *target, const float *weight,
+                     int B, int A, int HW, float beta, double *loss_sum, void *stream);
+int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const float *weight,
+                     int B, int A, int HW, float beta, float gscale, float *grad_pred,
+                     void *stream);
+
+/* IoU target (delta2bbox x2 + aligned bbox_overlaps,
+ * iou_aware_retina_head.py:256-259, mmdet/core/bbox/geometry.py:34-47) fused
+ * with weighted_iou_regression_loss (losses.py:460-480).  `level` selects the
+ * base anchors / H / W / stride of g.  iou_target (B*N_l, optional).
+ * bwd: grad_iou_pred NCHW (B,A,H,W); grad_bbox_pred NCHW (B,A*4,H,W) is the
+ * gradient THROUGH the IoU target (pass NULL for the detached variant).       */
+int ia_iou_bce_fwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
+                   int dtype, const float *bbox_targets, const float *bbox_weights, int B,
+                   float *iou_target, double *loss_sum, void *stream);
+int ia_iou_bce_bwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
+                   int dtype, const float *bbox_targets, const float *bbox_weights, int B,
+                   float gscale, float *grad_iou_pred, float *grad_bbox_pred, void *stream);
+
+/* mmdet.ops.sigmoid_focal_loss: sigmoid_focal_loss_cuda.forward / .backward
+ * (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-63,65-105;
+ * binding sigmoid_focal_loss.cpp:17-43).  logits (N,C) fp32, targets (N) int64,
+ * losses / d_losses / d_logits (N,C) fp32.                                    */
+int ia_sigmoid_focal_loss_fwd(const float *logits, const int64_t *targets, int N, int C,
+                              float gamma, float alpha, float *losses, void *stream);
+int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const float *d_losses,
+                              int N, int C, float gamma, float alpha, float *d_logits,
+                              void *stream);
+
+/* ------------------------------------------------------------------ self-test
+ * Elementwise fp32 math used by the kernels, exposed so tests can pin the
+ * device implementation bit-for-bit: op 0 exp, 1 log, 2 sigmoid, 3 sqrt,
+ * 4 x/y (y = second input), 5 sqrt(sigmoid(x)).                               */
+int ia_test_math(int op, const float *x, const float *y, float *out, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IOUAWARE_H */

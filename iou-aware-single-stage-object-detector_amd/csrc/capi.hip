@@ -1,0 +1,190 @@
+// C-ABI entry points of the inference half (see include/iouaware.h) and the
+// whole-path driver ia_get_bboxes: five launches on the caller's stream, no
+// host synchronisation, no allocation.
+#include <string.h>
+#include "ia_internal.hpp"
+#include "ia_math.hpp"
+
+namespace ia {
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void base_from_geom(const ia_head_geom *g, BaseAnchors &ba)
+{
+    memcpy(ba.v, g->base_anchors, sizeof(ba.v));
+}
+
+struct WsLayout { size_t off[6]; size_t total; int32_t N, R, Rs; };
+
+static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
+{
+    LevelTable t;
+    int rc = make_level_table(g, t);
+    if (rc) return rc;
+    if (batch < 1) return IA_E_ARG;
+    w.N = t.anchor_off[t.num_levels];
+    w.R = t.cand_off[t.num_levels];
+    if (w.R > IA_MAX_CANDIDATES) return IA_E_ARG;
+    w.Rs = (w.R + 63) / 64 * 64;
+    size_t o = 0;
+    const size_t B = (size_t)batch, C = (size_t)t.C;
+    w.off[0] = o; o = align_up(o + B * w.N * sizeof(float), 256);            // rowmax
+    w.off[1] = o; o = align_up(o + B * w.R * sizeof(int32_t), 256);          // cand_idx
+    w.off[2] = o; o = align_up(o + B * w.R * 4 * sizeof(float), 256);        // boxes
+    w.off[3] = o; o = align_up(o + B * C * w.Rs * sizeof(float), 256);       // scores_t
+    w.off[4] = o; o = align_up(o + B * C * sizeof(int32_t), 256);            // keep_count
+    w.off[5] = o; o = align_up(o + B * C * w.Rs * sizeof(int32_t), 256);     // keep_rows
+    w.total = o;
+    return 0;
+}
+
+__global__ void k_test_math(int op, const float *x, const float *y, float *out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[i], r;
+        switch (op) {
+        case 0: r = expf_(v); break;
+        case 1: r = logf_(v); break;
+        case 2: r = sigmoidf_(v); break;
+        case 3: r = __builtin_sqrtf(v); break;
+        case 4: r = v / y[i]; break;
+        default: r = sqrt_sigmoidf_(v); break;
+        }
+        out[i] = r;
+    }
+}
+
+}  // namespace ia
+
+extern "C" {
+
+const char *ia_version(void) { return "iouaware-hip 0.1 (gfx950)"; }
+
+int ia_geom_sizes(const ia_head_geom *g, int32_t *N, int32_t *R, int32_t *Rs)
+{
+    ia::WsLayout w;
+    int rc = ia::ws_layout(g, 1, w);
+    if (rc) return rc;
+    if (N) *N = w.N;
+    if (R) *R = w.R;
+    if (Rs) *Rs = w.Rs;
+    return 0;
+}
+
+int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                          float *rowmax, void *stream)
+{
+    ia::LevelTable t;
+    int rc = ia::make_level_table(g, t);
+    if (rc) return rc;
+    if (!p) return IA_E_ARG;
+    return ia::launch_rowmax(t, *p, batch, dtype, rowmax, (hipStream_t)stream);
+}
+
+int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_t *cand_idx,
+                   void *stream)
+{
+    ia::LevelTable t;
+    int rc = ia::make_level_table(g, t);
+    if (rc) return rc;
+    return ia::launch_select(t, rowmax, batch, cand_idx, (hipStream_t)stream);
+}
+
+int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                     const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
+                     int rescale, float *boxes, float *scores_t, void *stream)
+{
+    ia::WsLayout w;
+    int rc = ia::ws_layout(g, batch, w);
+    if (rc) return rc;
+    if (!p) return IA_E_ARG;
+    ia::LevelTable t;
+    ia::make_level_table(g, t);
+    ia::BaseAnchors ba;
+    ia::base_from_geom(g, ba);
+    return ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand_idx, img_hw,
+                             scale_factor, rescale, boxes, scores_t, w.Rs, (hipStream_t)stream);
+}
+
+int ia_multiclass_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
+                      float score_thr, float iou_thr, int max_per_img, float *dets,
+                      int32_t *labels, int32_t *rows, int32_t *num, int32_t *keep_count,
+                      int32_t *keep_rows, void *stream)
+{
+    const int Rs = (R + 63) / 64 * 64;
+    int rc = ia::launch_nms(boxes, scores_t, batch, R, Rs, C, score_thr, iou_thr, keep_count,
+                            keep_rows, (hipStream_t)stream);
+    if (rc) return rc;
+    return ia::launch_finalize(boxes, scores_t, keep_count, keep_rows, batch, R, Rs, C,
+                               max_per_img, dets, labels, rows, num, (hipStream_t)stream);
+}
+
+size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch)
+{
+    ia::WsLayout w;
+    if (ia::ws_layout(g, batch, w)) return 0;
+    return w.total;
+}
+
+int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[6])
+{
+    ia::WsLayout w;
+    int rc = ia::ws_layout(g, batch, w);
+    if (rc) return rc;
+    for (int i = 0; i < 6; ++i) offsets[i] = w.off[i];
+    return 0;
+}
+
+int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                  const float *img_hw, const float *scale_factor, int rescale, float score_thr,
+                  float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
+                  float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream)
+{
+    ia::WsLayout w;
+    int rc = ia::ws_layout(g, batch, w);
+    if (rc) return rc;
+    if (!p || !workspace) return IA_E_ARG;
+    if (workspace_bytes < w.total) return IA_E_WORKSPACE;
+    if (((uintptr_t)workspace & 255u) != 0) return IA_E_ARG;
+    char *ws = static_cast<char *>(workspace);
+    float *rowmax = reinterpret_cast<float *>(ws + w.off[0]);
+    int32_t *cand = reinterpret_cast<int32_t *>(ws + w.off[1]);
+    float *boxes = reinterpret_cast<float *>(ws + w.off[2]);
+    float *scores_t = reinterpret_cast<float *>(ws + w.off[3]);
+    int32_t *kc = reinterpret_cast<int32_t *>(ws + w.off[4]);
+    int32_t *kr = reinterpret_cast<int32_t *>(ws + w.off[5]);
+    hipStream_t s = (hipStream_t)stream;
+    ia::LevelTable t;
+    ia::make_level_table(g, t);
+    ia::BaseAnchors ba;
+    ia::base_from_geom(g, ba);
+    if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s))) return rc;
+    if ((rc = ia::launch_select(t, rowmax, batch, cand, s))) return rc;
+    if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
+                                scale_factor, rescale, boxes, scores_t, w.Rs, s)))
+        return rc;
+    if ((rc = ia::launch_nms(boxes, scores_t, batch, w.R, w.Rs, t.C, score_thr, iou_thr, kc, kr, s)))
+        return rc;
+    return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, dets,
+                               labels, rows, num, s);
+}
+
+int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *stream)
+{
+    return ia::launch_nms_single(dets, n, iou_thr, keep, count, (hipStream_t)stream);
+}
+
+int ia_test_math(int op, const float *x, const float *y, float *out, int64_t n, void *stream)
+{
+    if (n < 0 || op < 0 || op > 5) return IA_E_ARG;
+    if (n == 0) return 0;
+    if (!x || !out || (op == 4 && !y)) return IA_E_ARG;
+    int64_t blocks = (n + 255) / 256;
+    unsigned grid = (unsigned)(blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(ia::k_test_math, dim3(grid), dim3(256), 0, (hipStream_t)stream, op, x, y,
+                       out, n);
+    return ia::hip_status(hipGetLastError());
+}
+
+}  // extern "C"

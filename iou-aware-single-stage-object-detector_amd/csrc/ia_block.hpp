@@ -1,0 +1,164 @@
+// Workgroup-level primitives for gfx950 (wave64): radix top-k selection over a
+// virtual array of unique 64-bit keys, LDS bitonic sort, wave-aggregated LDS
+// histogram updates.  Used by the per-level top-k (select.hip) and the
+// per-image final top-k (nms.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ia {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t lane_prefix_popc(uint64_t mask)
+{
+    uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+    return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+}
+
+// LDS histogram increment with wave-level aggregation of the most common
+// digits: degenerate inputs (all keys equal -> one hot bin) would otherwise
+// serialise 64-way on a single LDS address.
+__device__ __forceinline__ void hist_add(uint32_t *hist, bool active, uint32_t digit)
+{
+    uint64_t act = __ballot(active);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (act == 0) break;
+        int leader = __builtin_ctzll(act);
+        uint32_t d0 = (uint32_t)__shfl((int)digit, leader);
+        uint64_t same = __ballot(active && digit == d0);
+        if (lane_id() == leader) atomicAdd(&hist[d0], (uint32_t)__builtin_popcountll(same));
+        if (active && digit == d0) active = false;
+        act &= ~same;
+    }
+    if (active) atomicAdd(&hist[digit], 1u);
+}
+
+// Descending bitonic sort of P (power of two) 64-bit keys in LDS by the whole
+// workgroup.  Caller must __syncthreads() before (keys written) -- the routine
+// ends with a barrier.
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t *keys, uint32_t P)
+{
+    const uint32_t nt = blockDim.x * blockDim.y;
+    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (P >> 1); t += nt) {
+                uint32_t pos = 2 * t - (t & (stride - 1));
+                uint32_t par = pos + stride;
+                bool up = ((pos & size) == 0);
+                uint64_t a = keys[pos], b = keys[par];
+                if ((a < b) == up) { keys[pos] = b; keys[par] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct TopkScratch {
+    uint32_t hist[2048];
+    uint32_t misc[8];   // 0: digit, 1: count above, 2: count in digit, 3: collect counter
+};
+
+// Select the k largest of n UNIQUE 64-bit keys key(i), i in [0,n), and leave
+// them sorted descending in sel[0..k).  sel must hold next_pow2(k) entries.
+// 1 <= k <= n.  Whole workgroup participates (blockDim.x*blockDim.y threads,
+// a multiple of 64, >= 64).  MSB-first radix select with 11/11/10-bit digits;
+// stops as soon as the digit bin equals the remaining need, so tie-free score
+// keys never touch the low (index) half.
+template <class KeyFn>
+__device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &sc, uint64_t *sel)
+{
+    const uint32_t nt = blockDim.x * blockDim.y;
+    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
+    uint64_t prefix = 0;
+    int bits_done = 0;
+    uint32_t need = k;
+    const int widths[6] = {11, 11, 10, 11, 11, 10};
+    for (int pass = 0; pass < 6; ++pass) {
+        const int wb = widths[pass];
+        const uint32_t nbins = 1u << wb;
+        const int shift = 64 - bits_done - wb;
+        for (uint32_t i = tid; i < nbins; i += nt) sc.hist[i] = 0;
+        __syncthreads();
+        const uint32_t n_up = (n + kWave - 1) & ~(uint32_t)(kWave - 1);
+        for (uint32_t i = tid; i < n_up; i += nt) {
+            bool act = i < n;
+            uint64_t x = act ? key(i) : 0;
+            if (bits_done > 0) act = act && ((x >> (64 - bits_done)) == prefix);
+            hist_add(sc.hist, act, (uint32_t)(x >> shift) & (nbins - 1));
+        }
+        __syncthreads();
+        // find the digit d (from the top) where the running count reaches `need`
+        if (tid < kWave) {
+            const uint32_t per = nbins / kWave;
+            const uint32_t hi_bin = nbins - per * tid;      // exclusive upper bin of this lane
+            uint32_t s = 0;
+            for (uint32_t j = 0; j < per; ++j) s += sc.hist[hi_bin - 1 - j];
+            uint32_t incl = s;
+            for (int off = 1; off < kWave; off <<= 1) {
+                uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                if ((int)tid >= off) incl += v;
+            }
+            uint64_t reach = __ballot(incl >= need);
+            int first = __builtin_ctzll(reach);            // reach != 0 because total >= need
+            if ((int)tid == first) {
+                uint32_t above = incl - s;
+                uint32_t d = hi_bin - 1;
+                for (uint32_t j = 0; j < per; ++j) {
+                    uint32_t c = sc.hist[hi_bin - 1 - j];
+                    if (above + c >= need) { d = hi_bin - 1 - j; sc.misc[2] = c; break; }
+                    above += c;
+                }
+                sc.misc[0] = d;
+                sc.misc[1] = above;
+            }
+        }
+        __syncthreads();
+        const uint32_t d = sc.misc[0], above = sc.misc[1], in_d = sc.misc[2];
+        need -= above;
+        prefix = (prefix << wb) | d;
+        bits_done += wb;
+        __syncthreads();
+        if (in_d == need) break;
+    }
+    // collect everything whose top `bits_done` bits are >= prefix: exactly k keys
+    if (tid == 0) sc.misc[3] = 0;
+    const uint32_t P = next_pow2(k);
+    for (uint32_t i = tid; i < P; i += nt) sel[i] = 0;
+    __syncthreads();
+    const int rs = 64 - bits_done;
+    const uint32_t n_up = (n + kWave - 1) & ~(uint32_t)(kWave - 1);
+    for (uint32_t i = tid; i < n_up; i += nt) {
+        bool act = i < n;
+        uint64_t x = act ? key(i) : 0;
+        bool take = act && ((rs == 0 ? x : (x >> rs)) >= prefix);
+        uint64_t m = __ballot(take);
+        if (m) {
+            uint32_t base = 0;
+            int leader = __builtin_ctzll(m);
+            if (lane_id() == leader) base = atomicAdd(&sc.misc[3], (uint32_t)__builtin_popcountll(m));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (take) {
+                uint32_t pos = base + lane_prefix_popc(m);
+                if (pos < P) sel[pos] = x;
+            }
+        }
+    }
+    __syncthreads();
+    bitonic_sort_desc(sel, P);
+}
+
+}  // namespace ia

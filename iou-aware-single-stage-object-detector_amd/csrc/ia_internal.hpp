@@ -1,0 +1,64 @@
+// Internal declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/iouaware.h"
+
+namespace ia {
+
+// per-level scalars used by kernels that do not need the base anchors
+struct LevelTable {
+    int32_t num_levels, A, C, nms_pre;
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], stride[IA_MAX_LEVELS];
+    int32_t anchor_off[IA_MAX_LEVELS + 1];   // prefix of N_l   (anchors per image)
+    int32_t cand_off[IA_MAX_LEVELS + 1];     // prefix of k_l   (candidates per image)
+    int32_t tile_off[IA_MAX_LEVELS + 1];     // prefix of ceil(HW_l / 256) row-max tiles
+};
+
+struct BaseAnchors { float v[IA_MAX_LEVELS][IA_MAX_ANCHORS][4]; };
+
+inline int make_level_table(const ia_head_geom *g, LevelTable &t)
+{
+    if (!g) return IA_E_ARG;
+    if (g->num_levels < 1 || g->num_levels > IA_MAX_LEVELS) return IA_E_ARG;
+    if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS) return IA_E_ARG;
+    if (g->num_classes < 1 || g->num_classes > 4096) return IA_E_ARG;
+    if (g->nms_pre > IA_MAX_NMS_PRE) return IA_E_ARG;
+    t.num_levels = g->num_levels; t.A = g->num_anchors; t.C = g->num_classes; t.nms_pre = g->nms_pre;
+    t.anchor_off[0] = t.cand_off[0] = t.tile_off[0] = 0;
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        bool on = l < g->num_levels;
+        if (on && (g->H[l] < 1 || g->W[l] < 1 || g->stride[l] < 1)) return IA_E_ARG;
+        t.H[l] = on ? g->H[l] : 0; t.W[l] = on ? g->W[l] : 0; t.stride[l] = on ? g->stride[l] : 0;
+        int64_t hw = (int64_t)t.H[l] * t.W[l];
+        int64_t nl = hw * t.A;
+        if (nl > (1 << 30)) return IA_E_ARG;
+        int32_t kl = (g->nms_pre > 0 && nl > g->nms_pre) ? g->nms_pre : (int32_t)nl;
+        t.anchor_off[l + 1] = t.anchor_off[l] + (int32_t)nl;
+        t.cand_off[l + 1] = t.cand_off[l] + kl;
+        t.tile_off[l + 1] = t.tile_off[l] + (int32_t)((hw + 255) / 256);
+    }
+    return 0;
+}
+
+// stage launchers (defined in the .hip files)
+int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
+                  hipStream_t s);
+int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
+                  hipStream_t s);
+int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
+                  const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
+                  const float *img_hw, const float *scale_factor, int rescale, float *boxes,
+                  float *scores_t, int Rs, hipStream_t s);
+int launch_nms(const float *boxes, const float *scores_t, int batch, int R, int Rs, int C,
+               float score_thr, float iou_thr, int32_t *keep_count, int32_t *keep_rows,
+               hipStream_t s);
+int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
+                    const int32_t *keep_rows, int batch, int R, int Rs, int C, int max_per_img,
+                    float *dets, int32_t *labels, int32_t *rows, int32_t *num, hipStream_t s);
+int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
+                      hipStream_t s);
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace ia

@@ -1,0 +1,468 @@
+// Training-loss kernels of IoUawareRetinaHead.loss_single
+// (reference iou_aware_retina_head.py:221-313), computed on the NCHW head
+// outputs without the permute/reshape copies, the (N,80) int64 one-hot
+// (anchor_target.py:247-254) or the (N,80) expanded weight the reference
+// materialises:
+//   focal      FocalLoss / py_sigmoid_focal_loss (losses.py:226-247,279-303)
+//   smooth-L1  weighted_smoothl1                 (losses.py:385-411)
+//   IoU-BCE    delta2bbox x2 + aligned IoU + BCE (head :256-259,:276-281;
+//                                                 geometry.py:34-47; losses.py:460-480)
+//   focal-op   the reference CUDA op's formula   (sigmoid_focal_loss_cuda.cu:23-105)
+//
+// All are streaming kernels; the dominant one (focal) re-uses the row-max
+// kernel's tiling: a wavefront owns one anchor and 256 consecutive positions,
+// so every class-plane access is a contiguous 1 KiB segment, and the label /
+// weight of an anchor are read once for all C classes.  Sums are reduced in
+// fp64 (wave shuffle -> LDS -> one fp64 atomic per workgroup).
+#include "ia_internal.hpp"
+#include "ia_math.hpp"
+#include "ia_block.hpp"
+
+namespace ia {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// every thread of the workgroup calls; one atomic per workgroup
+__device__ __forceinline__ void block_sum_to(double v, double *dst, double *lds /* >= 16 */)
+{
+    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t nw = (blockDim.x * blockDim.y + kWave - 1) / kWave;
+    v = wave_sum(v);
+    if ((tid & (kWave - 1)) == 0) lds[tid / kWave] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (uint32_t w = 0; w < nw; ++w) s += lds[w];
+        atomicAdd(dst, s);
+    }
+}
+
+// ------------------------------------------------------------------ focal
+struct FocalArgs {
+    const void *cls;
+    const int64_t *labels;
+    const float *label_weights;
+    double *loss_sum;
+    float *grad;
+    int32_t B, A, C, HW;
+    float gamma, alpha_pos, alpha_neg, gscale;
+};
+
+__device__ __forceinline__ void focal_elem(float x, bool t, float w0, const FocalArgs &a,
+                                           float &loss, float &grad, bool want_grad)
+{
+    float pr = sigmoidf_(x);
+    float pt = t ? (1.0f - pr) : pr;
+    float at = (t ? a.alpha_pos : a.alpha_neg) * w0;
+    float mod = powf_pos_(pt, a.gamma);
+    float W = at * mod;
+    float bce = bce_logits_(x, t ? 1.0f : 0.0f);
+    loss = bce * W;
+    if (want_grad) {
+        float dbce = pr - (t ? 1.0f : 0.0f);
+        float dpt = pr * (1.0f - pr);
+        dpt = t ? -dpt : dpt;
+        float dmod;
+        if (a.gamma == 2.0f) dmod = 2.0f * pt;
+        else if (a.gamma == 1.0f) dmod = 1.0f;
+        else if (a.gamma == 0.0f) dmod = 0.0f;
+        else dmod = a.gamma * powf_pos_(pt, a.gamma - 1.0f);
+        float g = dbce * W + (bce * at) * (dmod * dpt);
+        grad = g * a.gscale;
+    }
+}
+
+constexpr int kLossTile = 256;
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(1024) k_focal(FocalArgs a)
+{
+    __shared__ double red[16];
+    const int lane = threadIdx.x, an = threadIdx.y;
+    const int A = a.A, C = a.C, HW = a.HW;
+    const int tiles = (HW + kLossTile - 1) / kLossTile;
+    const int b = blockIdx.x / tiles;
+    const int p0 = (blockIdx.x - b * tiles) * kLossTile;
+    const T *cls = static_cast<const T *>(a.cls) + ((size_t)b * A + an) * C * HW;
+    float *grad = BWD ? a.grad + ((size_t)b * A + an) * C * HW : nullptr;
+    const size_t nbase = (size_t)b * HW * A;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + lane + 64 * j;
+        if (p >= HW) continue;
+        const size_t n = nbase + (size_t)p * A + an;
+        const int64_t lab = a.labels[n];
+        const float w0 = a.label_weights[n];
+        for (int c = 0; c < C; ++c) {
+            float x = load_f32<T>(cls + (size_t)c * HW + p);
+            float l, g = 0.0f;
+            focal_elem(x, lab == (int64_t)(c + 1), w0, a, l, g, BWD);
+            if (BWD) grad[(size_t)c * HW + p] = g;
+            else acc += (double)l;
+        }
+    }
+    if (!BWD) block_sum_to(acc, a.loss_sum, red);
+}
+
+static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *labels,
+                        const float *lw, int B, int A, int C, int HW, float gamma, float alpha,
+                        float gscale, double *loss_sum, float *grad, hipStream_t s)
+{
+    if (!cls || !labels || !lw || B < 1 || A < 1 || A > IA_MAX_ANCHORS || C < 1 || HW < 1)
+        return IA_E_ARG;
+    if (bwd ? !grad : !loss_sum) return IA_E_ARG;
+    FocalArgs a;
+    a.cls = cls; a.labels = labels; a.label_weights = lw; a.loss_sum = loss_sum; a.grad = grad;
+    a.B = B; a.A = A; a.C = C; a.HW = HW; a.gamma = gamma; a.gscale = gscale;
+    a.alpha_pos = alpha;
+    a.alpha_neg = (float)(1.0 - (double)alpha);   // python: (1 - alpha) in double, then fp32
+    dim3 block(64, A), grid((unsigned)(B * ((HW + kLossTile - 1) / kLossTile)));
+    if (dtype == IA_F32) {
+        if (bwd) hipLaunchKernelGGL((k_focal<float, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_focal<float, false>), grid, block, 0, s, a);
+    } else if (dtype == IA_BF16) {
+        if (bwd) hipLaunchKernelGGL((k_focal<uint16_t, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_focal<uint16_t, false>), grid, block, 0, s, a);
+    } else return IA_E_ARG;
+    return hip_status(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ smooth L1
+struct SmoothArgs {
+    const void *pred;
+    const float *target;
+    const float *weight;
+    double *loss_sum;
+    float *grad;
+    int32_t B, A, HW;
+    float beta, gscale;
+};
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
+{
+    __shared__ double red[16];
+    const int A = a.A, HW = a.HW;
+    const size_t total = (size_t)a.B * A * 4 * HW;
+    double acc = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const size_t q = e / HW;
+        const int k = (int)(q & 3);
+        const size_t ba = q >> 2;
+        const int an = (int)(ba % A);
+        const size_t b = ba / A;
+        const size_t n = ((b * HW + p) * A + an) * 4 + k;
+        float df = load_f32<T>(static_cast<const T *>(a.pred) + e) - a.target[n];
+        float d = __builtin_fabsf(df);
+        float w = a.weight[n];
+        if (BWD) {
+            float sgn = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
+            float g = (d < a.beta) ? df / a.beta : sgn;
+            a.grad[e] = (g * w) * a.gscale;
+        } else {
+            float l = (d < a.beta) ? ((0.5f * d) * d) / a.beta : d - 0.5f * a.beta;
+            acc += (double)(l * w);
+        }
+    }
+    if (!BWD) block_sum_to(acc, a.loss_sum, red);
+}
+
+static int launch_smooth(bool bwd, const void *pred, int dtype, const float *target,
+                         const float *weight, int B, int A, int HW, float beta, float gscale,
+                         double *loss_sum, float *grad, hipStream_t s)
+{
+    if (!pred || !target || !weight || B < 1 || A < 1 || HW < 1 || !(beta > 0.0f)) return IA_E_ARG;
+    if (bwd ? !grad : !loss_sum) return IA_E_ARG;
+    SmoothArgs a;
+    a.pred = pred; a.target = target; a.weight = weight; a.loss_sum = loss_sum; a.grad = grad;
+    a.B = B; a.A = A; a.HW = HW; a.beta = beta; a.gscale = gscale;
+    size_t total = (size_t)B * A * 4 * HW;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (dtype == IA_F32) {
+        if (bwd) hipLaunchKernelGGL((k_smooth_l1<float, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_smooth_l1<float, false>), dim3(grid), dim3(256), 0, s, a);
+    } else if (dtype == IA_BF16) {
+        if (bwd) hipLaunchKernelGGL((k_smooth_l1<uint16_t, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_smooth_l1<uint16_t, false>), dim3(grid), dim3(256), 0, s, a);
+    } else return IA_E_ARG;
+    return hip_status(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ IoU target + BCE
+struct Dec { float x1, y1, x2, y2, gw, gh, pw, ph; bool win, hin; };
+
+__device__ __forceinline__ Dec decode_free(const float (&anc)[4], const float (&d)[4],
+                                           const float *means, const float *stds)
+{
+    const float max_ratio = 4.135166556742356f;
+    Dec r;
+    float dx = d[0] * stds[0] + means[0];
+    float dy = d[1] * stds[1] + means[1];
+    float dw = d[2] * stds[2] + means[2];
+    float dh = d[3] * stds[3] + means[3];
+    r.win = (dw >= -max_ratio) && (dw <= max_ratio);
+    r.hin = (dh >= -max_ratio) && (dh <= max_ratio);
+    dw = (dw < -max_ratio) ? -max_ratio : dw;  dw = (dw > max_ratio) ? max_ratio : dw;
+    dh = (dh < -max_ratio) ? -max_ratio : dh;  dh = (dh > max_ratio) ? max_ratio : dh;
+    float px = (anc[0] + anc[2]) * 0.5f;
+    float py = (anc[1] + anc[3]) * 0.5f;
+    r.pw = (anc[2] - anc[0]) + 1.0f;
+    r.ph = (anc[3] - anc[1]) + 1.0f;
+    r.gw = r.pw * expf_(dw);
+    r.gh = r.ph * expf_(dh);
+    float gx = px + r.pw * dx;
+    float gy = py + r.ph * dy;
+    r.x1 = (gx - r.gw * 0.5f) + 0.5f;
+    r.y1 = (gy - r.gh * 0.5f) + 0.5f;
+    r.x2 = (gx + r.gw * 0.5f) - 0.5f;
+    r.y2 = (gy + r.gh * 0.5f) - 0.5f;
+    return r;
+}
+
+struct IouBceArgs {
+    const void *bbox_pred;
+    const void *iou_pred;
+    const float *bbox_targets;
+    const float *bbox_weights;
+    float *iou_target;
+    double *loss_sum;
+    float *grad_iou_pred;
+    float *grad_bbox_pred;
+    float base[IA_MAX_ANCHORS][4];
+    float means[4], stds[4];
+    int32_t B, A, H, W, stride;
+    float gscale;
+};
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
+{
+    __shared__ double red[16];
+    const int A = a.A, W = a.W, HW = a.H * a.W;
+    const size_t total = (size_t)a.B * A * HW;
+    double acc = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const size_t ba = e / HW;
+        const int an = (int)(ba % A);
+        const size_t b = ba / A;
+        const size_t n = (b * HW + p) * A + an;
+        const int y = p / W, x = p - y * W;
+        const float sx = (float)(x * a.stride), sy = (float)(y * a.stride);
+        const float anc[4] = {a.base[an][0] + sx, a.base[an][1] + sy, a.base[an][2] + sx,
+                              a.base[an][3] + sy};
+        const T *bp = static_cast<const T *>(a.bbox_pred) + ba * 4 * HW + p;
+        const float dp[4] = {load_f32<T>(bp), load_f32<T>(bp + (size_t)HW),
+                             load_f32<T>(bp + (size_t)2 * HW), load_f32<T>(bp + (size_t)3 * HW)};
+        const float4 tq = reinterpret_cast<const float4 *>(a.bbox_targets)[n];
+        const float dt[4] = {tq.x, tq.y, tq.z, tq.w};
+        Dec pb = decode_free(anc, dp, a.means, a.stds);
+        Dec tb = decode_free(anc, dt, a.means, a.stds);
+        float ltx = (tb.x1 < pb.x1) ? pb.x1 : tb.x1;
+        float lty = (tb.y1 < pb.y1) ? pb.y1 : tb.y1;
+        float rbx = (pb.x2 < tb.x2) ? pb.x2 : tb.x2;
+        float rby = (pb.y2 < tb.y2) ? pb.y2 : tb.y2;
+        float w0 = (rbx - ltx) + 1.0f, h0 = (rby - lty) + 1.0f;
+        float w = (w0 < 0.0f) ? 0.0f : w0, h = (h0 < 0.0f) ? 0.0f : h0;
+        float ov = w * h;
+        float a1 = ((tb.x2 - tb.x1) + 1.0f) * ((tb.y2 - tb.y1) + 1.0f);
+        float a2 = ((pb.x2 - pb.x1) + 1.0f) * ((pb.y2 - pb.y1) + 1.0f);
+        float un = (a1 + a2) - ov;
+        float t = ov / un;
+        float xl = load_f32<T>(static_cast<const T *>(a.iou_pred) + e);
+        float wt = a.bbox_weights[4 * n];
+        if (!BWD) {
+            if (a.iou_target) a.iou_target[n] = t;
+            acc += (double)(bce_logits_(xl, t) * wt);
+        } else {
+            if (a.grad_iou_pred) a.grad_iou_pred[e] = ((sigmoidf_(xl) - t) * wt) * a.gscale;
+            if (a.grad_bbox_pred) {
+                float gt = ((-xl) * wt) * a.gscale;
+                float inv_un = 1.0f / un;
+                float g_ov = gt * ((un + ov) * inv_un) * inv_un;
+                float g_a2 = gt * (-(ov * inv_un) * inv_un);
+                float g_w = (w0 >= 0.0f) ? g_ov * h : 0.0f;
+                float g_h = (h0 >= 0.0f) ? g_ov * w : 0.0f;
+                float pw2 = (pb.x2 - pb.x1) + 1.0f, ph2 = (pb.y2 - pb.y1) + 1.0f;
+                float gx1 = -g_a2 * ph2, gx2 = g_a2 * ph2;
+                float gy1 = -g_a2 * pw2, gy2 = g_a2 * pw2;
+                float sx1 = (pb.x1 > tb.x1) ? 1.0f : ((pb.x1 == tb.x1) ? 0.5f : 0.0f);
+                float sy1 = (pb.y1 > tb.y1) ? 1.0f : ((pb.y1 == tb.y1) ? 0.5f : 0.0f);
+                float sx2 = (pb.x2 < tb.x2) ? 1.0f : ((pb.x2 == tb.x2) ? 0.5f : 0.0f);
+                float sy2 = (pb.y2 < tb.y2) ? 1.0f : ((pb.y2 == tb.y2) ? 0.5f : 0.0f);
+                gx1 = gx1 - g_w * sx1;  gx2 = gx2 + g_w * sx2;
+                gy1 = gy1 - g_h * sy1;  gy2 = gy2 + g_h * sy2;
+                float g_gx = gx1 + gx2, g_gy = gy1 + gy2;
+                float g_gw = (gx2 - gx1) * 0.5f, g_gh = (gy2 - gy1) * 0.5f;
+                float *go = a.grad_bbox_pred + ba * 4 * HW + p;
+                go[0] = (g_gx * pb.pw) * a.stds[0];
+                go[(size_t)HW] = (g_gy * pb.ph) * a.stds[1];
+                go[(size_t)2 * HW] = pb.win ? (g_gw * pb.gw) * a.stds[2] : 0.0f;
+                go[(size_t)3 * HW] = pb.hin ? (g_gh * pb.gh) * a.stds[3] : 0.0f;
+            }
+        }
+    }
+    if (!BWD) block_sum_to(acc, a.loss_sum, red);
+}
+
+static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void *bbox_pred,
+                          const void *iou_pred, int dtype, const float *bt, const float *bw, int B,
+                          float gscale, float *iou_target, double *loss_sum, float *g_iou,
+                          float *g_box, hipStream_t s)
+{
+    if (!g || level < 0 || level >= g->num_levels || !bbox_pred || !iou_pred || !bt || !bw || B < 1)
+        return IA_E_ARG;
+    if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS) return IA_E_ARG;
+    if (!bwd && !loss_sum) return IA_E_ARG;
+    IouBceArgs a;
+    a.bbox_pred = bbox_pred; a.iou_pred = iou_pred; a.bbox_targets = bt; a.bbox_weights = bw;
+    a.iou_target = iou_target; a.loss_sum = loss_sum; a.grad_iou_pred = g_iou;
+    a.grad_bbox_pred = g_box;
+    for (int i = 0; i < IA_MAX_ANCHORS; ++i)
+        for (int k = 0; k < 4; ++k) a.base[i][k] = g->base_anchors[level][i][k];
+    for (int k = 0; k < 4; ++k) { a.means[k] = g->means[k]; a.stds[k] = g->stds[k]; }
+    a.B = B; a.A = g->num_anchors; a.H = g->H[level]; a.W = g->W[level];
+    a.stride = g->stride[level]; a.gscale = gscale;
+    size_t total = (size_t)B * a.A * a.H * a.W;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (dtype == IA_F32) {
+        if (bwd) hipLaunchKernelGGL((k_iou_bce<float, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_iou_bce<float, false>), dim3(grid), dim3(256), 0, s, a);
+    } else if (dtype == IA_BF16) {
+        if (bwd) hipLaunchKernelGGL((k_iou_bce<uint16_t, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_iou_bce<uint16_t, false>), dim3(grid), dim3(256), 0, s, a);
+    } else return IA_E_ARG;
+    return hip_status(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ focal op (CUDA-op formula)
+struct FocalOpArgs {
+    const float *logits;
+    const int64_t *targets;
+    const float *d_losses;
+    float *out;
+    int64_t total;
+    int32_t C;
+    float gamma, alpha;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_focal_op(FocalOpArgs a)
+{
+    const float FLT_MIN_ = 1.17549435e-38f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / a.C;
+        const int d = (int)(i - n * a.C);
+        const int t = (int)a.targets[n];
+        const float c1 = (t == d + 1) ? 1.0f : 0.0f;
+        const float c2 = ((t >= 0) & (t != d + 1)) ? 1.0f : 0.0f;
+        const float zn = 1.0f - a.alpha, zp = a.alpha;
+        const float x = a.logits[i];
+        const float p = 1.0f / (1.0f + expf_(-x));
+        const float pm = (p > FLT_MIN_) ? p : FLT_MIN_;
+        const float xs = (x >= 0.0f) ? x : 0.0f;
+        const float lg2 = (-1.0f * xs) - logf_(1.0f + expf_(x - 2.0f * xs));
+        float r = 0.0f;
+        if (!BWD) {
+            float term1 = powf_pos_(1.0f - p, a.gamma) * logf_(pm);
+            float term2 = powf_pos_(p, a.gamma) * lg2;
+            r += -c1 * term1 * zp;
+            r += -c2 * term2 * zn;
+        } else {
+            float term1 = powf_pos_(1.0f - p, a.gamma) * ((1.0f - p) - (p * a.gamma) * logf_(pm));
+            float term2 = powf_pos_(p, a.gamma) * ((lg2 * (1.0f - p)) * a.gamma - p);
+            r += -c1 * term1 * zp;
+            r += -c2 * term2 * zn;
+            r = r * a.d_losses[i];
+        }
+        a.out[i] = r;
+    }
+}
+
+static int launch_focal_op(bool bwd, const float *logits, const int64_t *targets,
+                           const float *d_losses, int N, int C, float gamma, float alpha,
+                           float *out, hipStream_t s)
+{
+    if (N < 0 || C < 1) return IA_E_ARG;
+    if (N == 0) return 0;
+    if (!logits || !targets || !out || (bwd && !d_losses)) return IA_E_ARG;
+    FocalOpArgs a;
+    a.logits = logits; a.targets = targets; a.d_losses = d_losses; a.out = out;
+    a.total = (int64_t)N * C; a.C = C; a.gamma = gamma; a.alpha = alpha;
+    int64_t blocks = (a.total + 255) / 256;
+    unsigned grid = (unsigned)(blocks > 4096 ? 4096 : blocks);
+    if (bwd) hipLaunchKernelGGL(k_focal_op<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_focal_op<false>, dim3(grid), dim3(256), 0, s, a);
+    return hip_status(hipGetLastError());
+}
+
+}  // namespace ia
+
+// ------------------------------------------------------------------ C ABI (loss half)
+extern "C" {
+
+int ia_focal_loss_fwd(const void *cls, int dtype, const int64_t *labels, const float *lw, int B,
+                      int A, int C, int HW, float gamma, float alpha, double *loss_sum, void *stream)
+{
+    return ia::launch_focal(false, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, 1.0f,
+                            loss_sum, nullptr, (hipStream_t)stream);
+}
+int ia_focal_loss_bwd(const void *cls, int dtype, const int64_t *labels, const float *lw, int B,
+                      int A, int C, int HW, float gamma, float alpha, float gscale, float *grad,
+                      void *stream)
+{
+    return ia::launch_focal(true, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, gscale,
+                            nullptr, grad, (hipStream_t)stream);
+}
+int ia_smooth_l1_fwd(const void *pred, int dtype, const float *target, const float *weight, int B,
+                     int A, int HW, float beta, double *loss_sum, void *stream)
+{
+    return ia::launch_smooth(false, pred, dtype, target, weight, B, A, HW, beta, 1.0f, loss_sum,
+                             nullptr, (hipStream_t)stream);
+}
+int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const float *weight, int B,
+                     int A, int HW, float beta, float gscale, float *grad, void *stream)
+{
+    return ia::launch_smooth(true, pred, dtype, target, weight, B, A, HW, beta, gscale, nullptr,
+                             grad, (hipStream_t)stream);
+}
+int ia_iou_bce_fwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
+                   int dtype, const float *bt, const float *bw, int B, float *iou_target,
+                   double *loss_sum, void *stream)
+{
+    return ia::launch_iou_bce(false, g, level, bbox_pred, iou_pred, dtype, bt, bw, B, 1.0f,
+                              iou_target, loss_sum, nullptr, nullptr, (hipStream_t)stream);
+}
+int ia_iou_bce_bwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
+                   int dtype, const float *bt, const float *bw, int B, float gscale, float *g_iou,
+                   float *g_box, void *stream)
+{
+    return ia::launch_iou_bce(true, g, level, bbox_pred, iou_pred, dtype, bt, bw, B, gscale,
+                              nullptr, nullptr, g_iou, g_box, (hipStream_t)stream);
+}
+int ia_sigmoid_focal_loss_fwd(const float *logits, const int64_t *targets, int N, int C,
+                              float gamma, float alpha, float *losses, void *stream)
+{
+    return ia::launch_focal_op(false, logits, targets, nullptr, N, C, gamma, alpha, losses,
+                               (hipStream_t)stream);
+}
+int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const float *d_losses,
+                              int N, int C, float gamma, float alpha, float *d_logits, void *stream)
+{
+    return ia::launch_focal_op(true, logits, targets, d_losses, N, C, gamma, alpha, d_logits,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

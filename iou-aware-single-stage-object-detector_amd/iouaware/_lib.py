@@ -1,0 +1,92 @@
+"""ctypes binding of libiouaware_hip.so (the C-ABI declared in include/iouaware.h).
+
+The library is the product: there is NO CPU / eager fallback.  If it is
+missing, importing an op raises; the kernels themselves only run on a gfx950
+device.
+"""
+import ctypes as C
+import os
+
+IA_MAX_LEVELS = 8
+IA_MAX_ANCHORS = 16
+IA_MAX_NMS_PRE = 4096
+IA_MAX_CANDIDATES = 8192
+IA_MAX_PER_IMG = 1024
+IA_F32, IA_BF16 = 0, 1
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
+SO_PATH = os.path.abspath(os.path.join(_CSRC, 'libiouaware_hip.so'))
+
+
+class HeadGeom(C.Structure):
+    _fields_ = [('num_levels', C.c_int32), ('num_anchors', C.c_int32),
+                ('num_classes', C.c_int32), ('nms_pre', C.c_int32),
+                ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS),
+                ('stride', C.c_int32 * IA_MAX_LEVELS),
+                ('base_anchors', ((C.c_float * 4) * IA_MAX_ANCHORS) * IA_MAX_LEVELS),
+                ('means', C.c_float * 4), ('stds', C.c_float * 4)]
+
+
+class LevelPtrs(C.Structure):
+    _fields_ = [('cls', C.c_void_p * IA_MAX_LEVELS), ('reg', C.c_void_p * IA_MAX_LEVELS),
+                ('iou', C.c_void_p * IA_MAX_LEVELS)]
+
+
+_vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+_G, _P = C.POINTER(HeadGeom), C.POINTER(LevelPtrs)
+
+# name -> (restype, argtypes); mirrors include/iouaware.h one to one
+SIGNATURES = {
+    'ia_version': (C.c_char_p, []),
+    'ia_geom_sizes': (_i, [_G, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'ia_decode_fuse_rowmax': (_i, [_G, _P, _i, _i, _vp, _vp]),
+    'ia_select_topk': (_i, [_G, _vp, _i, _vp, _vp]),
+    'ia_gather_decode': (_i, [_G, _P, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'ia_multiclass_nms': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
+    'ia_get_bboxes_workspace_bytes': (_sz, [_G, _i]),
+    'ia_get_bboxes': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _sz, _vp, _vp, _vp,
+                           _vp, _vp]),
+    'ia_get_bboxes_workspace_layout': (_i, [_G, _i, C.POINTER(_sz * 6)]),
+    'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
+    'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
+    'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    'ia_smooth_l1_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
+    'ia_iou_bce_fwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'ia_iou_bce_bwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    'ia_test_math': (_i, [_i, _vp, _vp, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+class IouAwareLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library.  Raises (never falls back) when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise IouAwareLibraryError(
+                'libiouaware_hip.so not found at %s: build it with '
+                '`python iou-aware-single-stage-object-detector_amd/csrc/build.py` '
+                '(hipcc, gfx950). There is no CPU fallback.' % SO_PATH)
+        h = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)     # AttributeError if the .so is stale: intended
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = 'argument error' if rc == -1 else ('workspace too small' if rc == -2 else
+                                                  'hipError_t %d' % rc)
+        raise IouAwareLibraryError('%s failed: %s' % (what, kind))

@@ -1,0 +1,397 @@
+"""torch-tensor front-end of the C-ABI kernels.
+
+PyTorch is plumbing here (device memory, streams); every function below
+launches hand-written gfx950 kernels through libiouaware_hip.so on the current
+torch stream and returns device tensors.  No function has a CPU path: tensors
+must live on a ROCm device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HeadGeom, LevelPtrs, IA_F32, IA_BF16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return IA_F32
+    if t.dtype == torch.bfloat16:
+        return IA_BF16
+    raise TypeError('head outputs must be float32 or bfloat16, got %s' % t.dtype)
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.IouAwareLibraryError(
+            '%s is on %s: the IoU-aware head kernels are gfx950 HIP kernels and have no CPU '
+            'fallback' % (name, t.device))
+
+
+class HeadGeometry(object):
+    """Static geometry of an anchor head for one set of feature-map sizes
+    (fills the C struct ia_head_geom)."""
+
+    def __init__(self, featmap_sizes, strides, base_anchors, num_classes, nms_pre=-1,
+                 means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+        base = np.asarray(base_anchors, dtype=np.float32)
+        L, A = base.shape[0], base.shape[1]
+        if L != len(featmap_sizes) or L != len(strides):
+            raise ValueError('level count mismatch')
+        if L > _lib.IA_MAX_LEVELS or A > _lib.IA_MAX_ANCHORS:
+            raise ValueError('unsupported head geometry (levels %d, anchors %d)' % (L, A))
+        g = HeadGeom()
+        g.num_levels, g.num_anchors, g.num_classes, g.nms_pre = L, A, int(num_classes), int(nms_pre)
+        for l, ((h, w), s) in enumerate(zip(featmap_sizes, strides)):
+            g.H[l], g.W[l], g.stride[l] = int(h), int(w), int(s)
+            for a in range(A):
+                for k in range(4):
+                    g.base_anchors[l][a][k] = float(base[l, a, k])
+        for k in range(4):
+            g.means[k], g.stds[k] = float(means[k]), float(stds[k])
+        self.struct = g
+        self.L, self.A, self.C = L, A, int(num_classes)
+        self.featmap_sizes = [tuple(int(v) for v in s) for s in featmap_sizes]
+        self.strides = [int(s) for s in strides]
+        n, r, rs = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().ia_geom_sizes(C.byref(g), C.byref(n), C.byref(r), C.byref(rs)),
+                   'ia_geom_sizes')
+        self.N, self.R, self.Rs = n.value, r.value, rs.value
+        self.level_anchors = [h * w * A for (h, w) in self.featmap_sizes]
+        self.level_cands = [min(nms_pre, n_) if nms_pre > 0 else n_ for n_ in self.level_anchors]
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def level_ptrs(geom, cls, reg, iou):
+    """Validate the per-level head outputs and pack their device pointers."""
+    if not (len(cls) == len(reg) == len(iou) == geom.L):
+        raise AssertionError('expected %d levels' % geom.L)
+    p = LevelPtrs()
+    B = cls[0].shape[0]
+    dt = _dtype_code(cls[0])
+    for l in range(geom.L):
+        h, w = geom.featmap_sizes[l]
+        for name, t, ch in (('cls_score', cls[l], geom.A * geom.C), ('bbox_pred', reg[l], geom.A * 4),
+                            ('iou_pred', iou[l], geom.A)):
+            _require_gpu(t, name)
+            if tuple(t.shape) != (B, ch, h, w):
+                raise AssertionError('%s level %d has shape %s, expected %s'
+                                     % (name, l, tuple(t.shape), (B, ch, h, w)))
+            if _dtype_code(t) != dt:
+                raise TypeError('mixed dtypes in head outputs')
+        cls[l] = cls[l].contiguous()
+        reg[l] = reg[l].contiguous()
+        iou[l] = iou[l].contiguous()
+        p.cls[l], p.reg[l], p.iou[l] = cls[l].data_ptr(), reg[l].data_ptr(), iou[l].data_ptr()
+    return p, B, dt
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _meta_tensors(img_shapes, scale_factors, device):
+    hw = torch.tensor([[float(s[0]), float(s[1])] for s in img_shapes], dtype=torch.float32)
+    sf = []
+    for s in scale_factors:
+        v = np.asarray(s, dtype=np.float32).reshape(-1)
+        sf.append(np.repeat(v, 4) if v.size == 1 else v)
+    sf = torch.from_numpy(np.stack(sf).astype(np.float32))
+    return hw.to(device, non_blocking=True), sf.to(device, non_blocking=True)
+
+
+def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr, iou_thr,
+               max_per_img, debug=False):
+    """Whole post-conv inference path for a batch.
+
+    Returns device tensors dets (B,max_per_img,5) f32, labels (B,max_per_img) i32,
+    rows (B,max_per_img) i32 (candidate row ids), num (B) i32.  With debug=True
+    also returns the workspace views (rowmax, cand_idx, boxes, scores_t,
+    keep_count, keep_rows) for stage-level parity tests.
+    """
+    cls, reg, iou = list(cls), list(reg), list(iou)
+    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    dev = cls[0].device
+    L = _lib.lib()
+    nbytes = L.ia_get_bboxes_workspace_bytes(geom.ref(), B)
+    if nbytes == 0:
+        raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_get_bboxes')
+    ws = _workspace(dev, nbytes)
+    hw, sf = _meta_tensors(img_shapes, scale_factors, dev)
+    dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    rows = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    rc = L.ia_get_bboxes(geom.ref(), C.byref(p), B, dt, _ptr(hw), _ptr(sf), int(bool(rescale)),
+                         float(score_thr), float(iou_thr), int(max_per_img), _ptr(ws), nbytes,
+                         _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _stream())
+    _lib.check(rc, 'ia_get_bboxes')
+    if not debug:
+        return dets, labels, rows, num
+    off = (C.c_size_t * 6)()
+    _lib.check(L.ia_get_bboxes_workspace_layout(geom.ref(), B, C.byref(off)), 'workspace_layout')
+
+    def view(i, dtype, shape):
+        n = int(np.prod(shape))
+        return ws[off[i]:off[i] + n * 4].view(dtype).view(*shape)
+    dbg = dict(rowmax=view(0, torch.float32, (B, geom.N)),
+               cand_idx=view(1, torch.int32, (B, geom.R)),
+               boxes=view(2, torch.float32, (B, geom.R, 4)),
+               scores_t=view(3, torch.float32, (B, geom.C, geom.Rs)),
+               keep_count=view(4, torch.int32, (B, geom.C)),
+               keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)))
+    return dets, labels, rows, num, dbg
+
+
+# ----------------------------------------------------------------- stage wrappers
+def decode_fuse_rowmax(geom, cls, reg, iou):
+    cls, reg, iou = list(cls), list(reg), list(iou)
+    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    out = torch.empty((B, geom.N), dtype=torch.float32, device=cls[0].device)
+    _lib.check(_lib.lib().ia_decode_fuse_rowmax(geom.ref(), C.byref(p), B, dt, _ptr(out),
+                                                _stream()), 'ia_decode_fuse_rowmax')
+    return out
+
+
+def select_topk(geom, rowmax):
+    _require_gpu(rowmax, 'rowmax')
+    rowmax = rowmax.contiguous()
+    B = rowmax.shape[0]
+    out = torch.empty((B, geom.R), dtype=torch.int32, device=rowmax.device)
+    _lib.check(_lib.lib().ia_select_topk(geom.ref(), _ptr(rowmax), B, _ptr(out), _stream()),
+               'ia_select_topk')
+    return out
+
+
+def gather_decode(geom, cls, reg, iou, cand_idx, img_shapes, scale_factors, rescale):
+    cls, reg, iou = list(cls), list(reg), list(iou)
+    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    dev = cls[0].device
+    hw, sf = _meta_tensors(img_shapes, scale_factors, dev)
+    boxes = torch.empty((B, geom.R, 4), dtype=torch.float32, device=dev)
+    scores_t = torch.zeros((B, geom.C, geom.Rs), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().ia_gather_decode(geom.ref(), C.byref(p), B, dt, _ptr(cand_idx), _ptr(hw),
+                                           _ptr(sf), int(bool(rescale)), _ptr(boxes),
+                                           _ptr(scores_t), _stream()), 'ia_gather_decode')
+    return boxes, scores_t
+
+
+def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img):
+    """boxes (B,R,4), scores_t (B,C,Rs) class-major."""
+    _require_gpu(boxes, 'boxes')
+    B, Cn, Rs = scores_t.shape
+    dev = boxes.device
+    dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    rows = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    kc = torch.empty((B, Cn), dtype=torch.int32, device=dev)
+    kr = torch.empty((B, Cn, Rs), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().ia_multiclass_nms(_ptr(boxes.contiguous()), _ptr(scores_t.contiguous()),
+                                            B, int(R), Cn, float(score_thr), float(iou_thr),
+                                            int(max_per_img), _ptr(dets), _ptr(labels), _ptr(rows),
+                                            _ptr(num), _ptr(kc), _ptr(kr), _stream()),
+               'ia_multiclass_nms')
+    return dets, labels, rows, num, kc, kr
+
+
+def nms_indices(dets, iou_thr):
+    """Device NMS on (n,5) fp32 dets; returns ascending kept indices (int64, device)."""
+    _require_gpu(dets, 'dets')
+    n = dets.shape[0]
+    if n == 0:
+        return dets.new_zeros(0, dtype=torch.long)
+    if n > _lib.IA_MAX_CANDIDATES:
+        raise _lib.IouAwareLibraryError('nms supports at most %d boxes per call, got %d'
+                                        % (_lib.IA_MAX_CANDIDATES, n))
+    d = dets.detach().to(torch.float32).contiguous()
+    keep = torch.empty((n,), dtype=torch.int32, device=dets.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    _lib.check(_lib.lib().ia_nms(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _stream()),
+               'ia_nms')
+    m = int(cnt.item())
+    return keep[:m].to(torch.long)
+
+
+def test_math(op, x, y=None):
+    _require_gpu(x, 'x')
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().ia_test_math(int(op), _ptr(x), _ptr(y.contiguous() if y is not None else None),
+                                       _ptr(out), x.numel(), _stream()), 'ia_test_math')
+    return out
+
+
+# ----------------------------------------------------------------- training losses
+class _FocalLossFn(torch.autograd.Function):
+    """sum over the level of py_sigmoid_focal_loss on NCHW logits."""
+
+    @staticmethod
+    def forward(ctx, cls, labels, label_weights, A, gamma, alpha):
+        _require_gpu(cls, 'cls_score')
+        cls = cls.contiguous()
+        B, ch, H, W = cls.shape
+        Cn = ch // A
+        labels = labels.contiguous().view(-1).to(torch.int64)
+        lw = label_weights.contiguous().view(-1).to(torch.float32)
+        acc = torch.zeros(1, dtype=torch.float64, device=cls.device)
+        _lib.check(_lib.lib().ia_focal_loss_fwd(_ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw),
+                                                B, A, Cn, H * W, float(gamma), float(alpha),
+                                                _ptr(acc), _stream()), 'ia_focal_loss_fwd')
+        ctx.save_for_backward(cls, labels, lw)
+        ctx.cfg = (A, Cn, float(gamma), float(alpha))
+        return acc.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        cls, labels, lw = ctx.saved_tensors
+        A, Cn, gamma, alpha = ctx.cfg
+        B, ch, H, W = cls.shape
+        grad = torch.empty(cls.shape, dtype=torch.float32, device=cls.device)
+        _lib.check(_lib.lib().ia_focal_loss_bwd(_ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw),
+                                                B, A, Cn, H * W, gamma, alpha, float(g.item()),
+                                                _ptr(grad), _stream()), 'ia_focal_loss_bwd')
+        return grad.to(cls.dtype), None, None, None, None, None
+
+
+def focal_loss_sum(cls, labels, label_weights, num_anchors, gamma=2.0, alpha=0.25):
+    return _FocalLossFn.apply(cls, labels, label_weights, num_anchors, gamma, alpha)
+
+
+class _SmoothL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, A, beta):
+        _require_gpu(pred, 'bbox_pred')
+        pred = pred.contiguous()
+        B, ch, H, W = pred.shape
+        target = target.contiguous().to(torch.float32)
+        weight = weight.contiguous().to(torch.float32)
+        acc = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ia_smooth_l1_fwd(_ptr(pred), _dtype_code(pred), _ptr(target),
+                                               _ptr(weight), B, A, H * W, float(beta), _ptr(acc),
+                                               _stream()), 'ia_smooth_l1_fwd')
+        ctx.save_for_backward(pred, target, weight)
+        ctx.cfg = (A, float(beta))
+        return acc.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, weight = ctx.saved_tensors
+        A, beta = ctx.cfg
+        B, ch, H, W = pred.shape
+        grad = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.lib().ia_smooth_l1_bwd(_ptr(pred), _dtype_code(pred), _ptr(target),
+                                               _ptr(weight), B, A, H * W, beta, float(g.item()),
+                                               _ptr(grad), _stream()), 'ia_smooth_l1_bwd')
+        return grad.to(pred.dtype), None, None, None, None
+
+
+def smooth_l1_sum(pred, target, weight, num_anchors, beta):
+    return _SmoothL1Fn.apply(pred, target, weight, num_anchors, beta)
+
+
+class _IouBceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target):
+        _require_gpu(bbox_pred, 'bbox_pred')
+        bbox_pred, iou_pred = bbox_pred.contiguous(), iou_pred.contiguous()
+        if bbox_pred.dtype != iou_pred.dtype:
+            raise TypeError('bbox_pred / iou_pred dtype mismatch')
+        B = bbox_pred.shape[0]
+        bt = bbox_targets.contiguous().to(torch.float32)
+        bw = bbox_weights.contiguous().to(torch.float32)
+        acc = torch.zeros(1, dtype=torch.float64, device=bbox_pred.device)
+        _lib.check(_lib.lib().ia_iou_bce_fwd(geom.ref(), int(level), _ptr(bbox_pred), _ptr(iou_pred),
+                                             _dtype_code(bbox_pred), _ptr(bt), _ptr(bw), B,
+                                             C.c_void_p(0), _ptr(acc), _stream()),
+                   'ia_iou_bce_fwd')
+        ctx.save_for_backward(bbox_pred, iou_pred, bt, bw)
+        ctx.cfg = (geom, int(level), bool(attach_target))
+        return acc.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        bbox_pred, iou_pred, bt, bw = ctx.saved_tensors
+        geom, level, attach = ctx.cfg
+        B = bbox_pred.shape[0]
+        g_iou = torch.empty(iou_pred.shape, dtype=torch.float32, device=iou_pred.device)
+        g_box = torch.empty(bbox_pred.shape, dtype=torch.float32,
+                            device=bbox_pred.device) if attach else None
+        _lib.check(_lib.lib().ia_iou_bce_bwd(geom.ref(), level, _ptr(bbox_pred), _ptr(iou_pred),
+                                             _dtype_code(bbox_pred), _ptr(bt), _ptr(bw), B,
+                                             float(g.item()), _ptr(g_iou), _ptr(g_box), _stream()),
+                   'ia_iou_bce_bwd')
+        return (g_box.to(bbox_pred.dtype) if attach else None, g_iou.to(iou_pred.dtype), None,
+                None, None, None, None)
+
+
+def iou_bce_sum(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target=True):
+    return _IouBceFn.apply(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level,
+                           attach_target)
+
+
+def iou_targets(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level):
+    """The IoU regression targets of one level (B*N_l) -- for tests / analysis."""
+    B = bbox_pred.shape[0]
+    h, w = geom.featmap_sizes[level]
+    out = torch.empty(B * h * w * geom.A, dtype=torch.float32, device=bbox_pred.device)
+    acc = torch.zeros(1, dtype=torch.float64, device=bbox_pred.device)
+    _lib.check(_lib.lib().ia_iou_bce_fwd(geom.ref(), int(level), _ptr(bbox_pred.contiguous()),
+                                         _ptr(iou_pred.contiguous()), _dtype_code(bbox_pred),
+                                         _ptr(bbox_targets.contiguous()),
+                                         _ptr(bbox_weights.contiguous()), B, _ptr(out), _ptr(acc),
+                                         _stream()), 'ia_iou_bce_fwd')
+    return out, acc
+
+
+class _SigmoidFocalLossOpFn(torch.autograd.Function):
+    """the reference's mmdet.ops.sigmoid_focal_loss op (integer targets, no weights)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, gamma, alpha):
+        _require_gpu(logits, 'input')
+        if logits.dim() != 2:
+            raise RuntimeError('logits should be NxClass')
+        x = logits.contiguous().to(torch.float32)
+        t = targets.contiguous().to(torch.int64)
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().ia_sigmoid_focal_loss_fwd(_ptr(x), _ptr(t), x.shape[0], x.shape[1],
+                                                        float(gamma), float(alpha), _ptr(out),
+                                                        _stream()), 'ia_sigmoid_focal_loss_fwd')
+        ctx.save_for_backward(x, t)
+        ctx.cfg = (float(gamma), float(alpha), logits.dtype)
+        return out.to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        x, t = ctx.saved_tensors
+        gamma, alpha, dt = ctx.cfg
+        d = d_loss.contiguous().to(torch.float32)
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().ia_sigmoid_focal_loss_bwd(_ptr(x), _ptr(t), _ptr(d), x.shape[0],
+                                                        x.shape[1], gamma, alpha, _ptr(out),
+                                                        _stream()), 'ia_sigmoid_focal_loss_bwd')
+        return out.to(dt), None, None, None
+
+
+def sigmoid_focal_loss_elementwise(logits, targets, gamma=2.0, alpha=0.25):
+    return _SigmoidFocalLossOpFn.apply(logits, targets, gamma, alpha)

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI shared library builds, loads and exports every function that
+include/iouaware.h declares (no compute: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+HEADER = os.path.join(ROOT, 'include', 'iouaware.h')
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ia_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = declared_functions()
+    for must in ('ia_get_bboxes', 'ia_decode_fuse_rowmax', 'ia_select_topk', 'ia_gather_decode',
+                 'ia_multiclass_nms', 'ia_nms', 'ia_focal_loss_fwd', 'ia_focal_loss_bwd',
+                 'ia_smooth_l1_fwd', 'ia_smooth_l1_bwd', 'ia_iou_bce_fwd', 'ia_iou_bce_bwd',
+                 'ia_sigmoid_focal_loss_fwd', 'ia_sigmoid_focal_loss_bwd'):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from iouaware import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            'ia_build', os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd', 'csrc',
+                                     'build.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    h = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared_functions():
+        assert hasattr(h, name), 'missing export %s' % name
+    # the python binding table mirrors the header one to one
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    assert b'gfx950' in _lib.lib().ia_version()
+
+
+def test_struct_layout_matches_header():
+    from iouaware import _lib
+    # 4 ints + 3*8 ints + 8*16*4 floats + 8 floats
+    assert ctypes.sizeof(_lib.HeadGeom) == 4 * 4 + 3 * 8 * 4 + 8 * 16 * 4 * 4 + 8 * 4
+    assert ctypes.sizeof(_lib.LevelPtrs) == 3 * 8 * 8
+
+
+def test_geometry_sizes_match_survey_table():
+    import numpy as np
+    from iouaware import ops
+    import synth
+    sizes = synth.level_shapes(800, 1344)
+    assert sizes == [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    base = np.zeros((5, 9, 4), np.float32)
+    g = ops.HeadGeometry(sizes, synth.STRIDES, base, 80, nms_pre=1000)
+    assert (g.N, g.R, g.Rs) == (201600, 4693, 4736)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from iouaware import ops, _lib
+    with pytest.raises(_lib.IouAwareLibraryError):
+        ops.nms_indices(torch.zeros(3, 5), 0.5)

@@ -1,0 +1,281 @@
+"""GPU (MI355X): the HIP path, called through the C-ABI, against the CPU oracle
+on the same seeded inputs and against the reference-generated golden fixtures.
+
+Bars
+  * HIP vs oracle: BIT-EXACT for every float and every index (the kernels and
+    the oracle restate the same IEEE operation sequence), on all inputs
+    including heavy ties.
+  * HIP vs golden (the reference itself): indices bit-exact, floats
+    |a-b| <= 1e-4 * max(1,|b|)  (north_star tolerance 1e-4 fp32).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from iouaware import ops as o
+    return o
+
+
+# ------------------------------------------------------------------ device math
+def test_device_math_is_bit_identical_to_oracle(ops, oracle_lib):
+    rs = np.random.RandomState(3)
+    x = np.concatenate([
+        rs.standard_normal(400000) * 8, rs.uniform(-104, 89, 200000), rs.uniform(-1e-3, 1e-3, 1000),
+        [0.0, -0.0, 1.0, -1.0, 88.72, 88.73, -87.3, -103.9, -104.0, 4.1351666, -4.1351666,
+         1e-38, -1e-38, 1e-45, 16.6, -16.6, 17.0, -17.0]]).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    for op, name in ((0, 'expf'), (2, 'sigmoidf')):
+        assert G.same_bits(ops.test_math(op, xd).cpu().numpy(), oracle_lib.vec(name, x)), name
+    pos = np.abs(x) + np.float32(1e-30)
+    assert G.same_bits(ops.test_math(1, torch.from_numpy(pos).cuda()).cpu().numpy(),
+                       oracle_lib.vec('logf', pos))
+    # correctly rounded sqrt and divide (hipcc default) == numpy fp32
+    assert G.same_bits(ops.test_math(3, torch.from_numpy(pos).cuda()).cpu().numpy(), np.sqrt(pos))
+    y = (rs.uniform(0.1, 1000, x.size)).astype(np.float32)
+    assert G.same_bits(ops.test_math(4, xd, torch.from_numpy(y).cuda()).cpu().numpy(), x / y)
+    sq = np.sqrt(oracle_lib.vec('sigmoidf', x))
+    assert G.same_bits(ops.test_math(5, xd).cpu().numpy(), sq)
+
+
+# ------------------------------------------------------------------ stages
+def oracle_image(oracle_lib, cls, reg, iou, b, base, img_hw, sf, rescale, nms_pre, score_thr,
+                 iou_thr, max_per_img, means=(0, 0, 0, 0), stds=(1, 1, 1, 1)):
+    return oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
+                                        [x[b] for x in iou], synth.STRIDES, base, img_hw, sf,
+                                        rescale, nms_pre, score_thr, iou_thr, max_per_img,
+                                        means=means, stds=stds)
+
+
+def check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr,
+                         iou_thr, max_per_img, dtype=torch.float32, means=(0, 0, 0, 0),
+                         stds=(1, 1, 1, 1)):
+    """runs the whole HIP path with debug views and compares every stage bit for bit"""
+    B = cls[0].shape[0]
+    dc, dr, di = G.to_dev(cls, dtype), G.to_dev(reg, dtype), G.to_dev(iou, dtype)
+    shapes = [m['img_shape'] for m in metas]
+    sfs = [m['scale_factor'] for m in metas]
+    dets, labels, rows, num, dbg = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale,
+                                                  score_thr, iou_thr, max_per_img, debug=True)
+    torch.cuda.synchronize()
+    dets, labels, rows, num = dets.cpu().numpy(), labels.cpu().numpy(), rows.cpu().numpy(), \
+        num.cpu().numpy()
+    dbg = {k: v.cpu().numpy() for k, v in dbg.items()}
+    out = []
+    for b in range(B):
+        o = oracle_image(oracle_lib, cls, reg, iou, b, base, shapes[b][:2], sfs[b], rescale,
+                         geom.struct.nms_pre, score_thr, iou_thr, max_per_img, means, stds)
+        assert G.same_bits(dbg['rowmax'][b], o['rowmax']), 'rowmax img %d' % b
+        assert np.array_equal(dbg['cand_idx'][b], o['topk_inds']), 'topk img %d' % b
+        assert G.same_bits(dbg['boxes'][b], o['mlvl_bboxes']), 'boxes img %d' % b
+        assert G.same_bits(dbg['scores_t'][b][:, :geom.R].T, o['mlvl_scores']), 'scores img %d' % b
+        assert np.array_equal(dbg['keep_count'][b], o['keep_count']), 'keep_count img %d' % b
+        for c in range(geom.C):
+            k = o['keep_count'][c]
+            assert np.array_equal(dbg['keep_rows'][b, c, :k], o['keep_rows'][c, :k]), (b, c)
+        n = int(num[b])
+        assert n == o['num_det']
+        assert G.same_bits(dets[b, :n], o['det_bboxes'])
+        assert np.array_equal(labels[b, :n], o['det_labels'])
+        assert np.array_equal(rows[b, :n], o['det_rows'])
+        assert (labels[b, n:] == -1).all() and (dets[b, n:] == 0).all()
+        out.append(dict(det_bboxes=dets[b, :n], det_labels=labels[b, :n], det_rows=rows[b, :n],
+                        topk_inds=dbg['cand_idx'][b], keep_count=dbg['keep_count'][b],
+                        keep_rows=np.concatenate([dbg['keep_rows'][b, c, :dbg['keep_count'][b, c]]
+                                                  for c in range(geom.C)])))
+    return out
+
+
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C'])
+def test_get_bboxes_vs_oracle_and_golden(ops, oracle_lib, golden_dir, name):
+    f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    B = int(f['batch'])
+    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    assert synth.checksum(cls + reg + iou) == int(f['checksum'])
+    geom, base = G.geometry(ph, pw, int(f['nms_pre']))
+    metas = [synth.img_meta(ih, iw, ph, pw, float(f['scale_factors'][b])) for b in range(B)]
+    res = check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas,
+                               bool(f['rescale']), float(f['score_thr']), float(f['iou_thr']),
+                               int(f['max_per_img']))
+    for b, r in enumerate(res):     # and against the reference's own outputs
+        assert np.array_equal(r['topk_inds'], f['topk_inds_%d' % b])
+        assert np.array_equal(r['keep_count'], f['keep_count_%d' % b])
+        assert np.array_equal(r['keep_rows'], f['keep_rows_%d' % b])
+        assert np.array_equal(r['det_labels'], f['det_labels_%d' % b])
+        assert np.array_equal(r['det_rows'], f['det_rows_%d' % b])
+        assert G.close(r['det_bboxes'], f['det_bboxes_%d' % b], 1e-4)
+
+
+def test_heavy_ties_random_init_like(ops, oracle_lib):
+    """BASELINE config 1: random-init weights give almost constant logits, every fused score
+    in [0.0704, 0.0710] with rampant fp32 ties.  Canonical order (score desc,
+    index asc) must hold bit for bit, including ties AT the k boundary."""
+    ph, pw, B = 128, 160, 2
+    rs = np.random.RandomState(8)
+    cls, reg, iou = [], [], []
+    for (h, w) in synth.level_shapes(ph, pw):
+        # few distinct values -> massive ties
+        cls.append((-4.595 + rs.randint(-3, 4, (B, 720, h, w)) * 0.0016).astype(np.float32))
+        reg.append((rs.standard_normal((B, 36, h, w)) * 0.01).astype(np.float32))
+        iou.append((rs.randint(-2, 3, (B, 9, h, w)) * 0.0019).astype(np.float32))
+    geom, base = G.geometry(ph, pw, 1000)
+    metas = [synth.img_meta(120, 157, ph, pw, 1.0) for _ in range(B)]
+    check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, 100)
+    # all logits identical: every anchor ties
+    cls = [np.full_like(c, -4.595) for c in cls]
+    iou = [np.zeros_like(i) for i in iou]
+    check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, 100)
+
+
+def test_target_stds_and_no_rescale(ops, oracle_lib):
+    ph, pw = 96, 128
+    cls, reg, iou = synth.head_outputs(77, 1, ph, pw, 'B')
+    stds = (0.1, 0.1, 0.2, 0.2)
+    means = (0.01, -0.02, 0.03, 0.0)
+    geom, base = G.geometry(ph, pw, 500, means, stds)
+    metas = [synth.img_meta(90, 121, ph, pw, 1.0)]
+    check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, False, 0.1, 0.45, 64,
+                         means=means, stds=stds)
+
+
+def test_nothing_passes_score_thr(ops, oracle_lib):
+    ph, pw = 64, 64
+    cls, reg, iou = synth.head_outputs(5, 1, ph, pw, 'A')
+    cls = [c - 30.0 for c in cls]
+    geom, base = G.geometry(ph, pw, 1000)
+    metas = [synth.img_meta(64, 64, ph, pw, 1.0)]
+    res = check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5,
+                               100)
+    assert res[0]['det_bboxes'].shape == (0, 5)      # bbox_nms.py:57-59 empty result
+
+
+def test_bf16_inputs(ops, oracle_lib):
+    """config 3: bf16 feature maps, fp32 math.  The oracle is fed the same bf16-rounded values."""
+    ph, pw = 128, 160
+    cls, reg, iou = synth.head_outputs(31, 2, ph, pw, 'A')
+    cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
+    geom, base = G.geometry(ph, pw, 1000)
+    metas = [synth.img_meta(120, 157, ph, pw, 1.0), synth.img_meta(120, 157, ph, pw, 2.0)]
+    check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, 100,
+                         dtype=torch.bfloat16)
+
+
+def test_stage_entry_points(ops, oracle_lib):
+    """the four stage entry points chained by hand equal the fused driver"""
+    ph, pw = 128, 160
+    cls, reg, iou = synth.head_outputs(9, 2, ph, pw, 'A')
+    geom, base = G.geometry(ph, pw, 300)
+    dc, dr, di = G.to_dev(cls), G.to_dev(reg), G.to_dev(iou)
+    shapes, sfs = [(120, 157, 3)] * 2, [1.0, 1.3]
+    rm = ops.decode_fuse_rowmax(geom, dc, dr, di)
+    idx = ops.select_topk(geom, rm)
+    boxes, scores_t = ops.gather_decode(geom, dc, dr, di, idx, shapes, sfs, True)
+    d1 = ops.multiclass_nms(boxes, scores_t, geom.R, 0.05, 0.5, 100)
+    d2 = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, True, 0.05, 0.5, 100)
+    torch.cuda.synchronize()
+    for a, b in zip(d1[:4], d2):
+        assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ nms op
+def test_nms_op_golden_cases(ops, golden_dir):
+    n = np.load(os.path.join(golden_dir, 'nms.npz'))
+    for i in range(int(n['num_cases'])):
+        d = torch.from_numpy(n['dets_%d' % i]).cuda().view(-1, 5)
+        keep = ops.nms_indices(d, float(n['thr_%d' % i])).cpu().numpy()
+        assert np.array_equal(keep, n['keep_%d' % i]), 'case %d' % i
+    for j in range(2):      # the ">=" corner (nms_cpu.cpp:55)
+        d = torch.from_numpy(n['edge_dets_%d' % j]).cuda()
+        keep = ops.nms_indices(d, float(n['edge_thr_%d' % j])).cpu().numpy()
+        assert np.array_equal(keep, n['edge_keep_%d' % j])
+
+
+def test_nms_op_threshold_rounding_adversarial(ops, oracle_lib):
+    """pairs whose exact IoU sits within an ulp of the threshold: the fp64 mid-point test in
+    the kernel must reproduce fl32(inter/union) >= thr exactly."""
+    rs = np.random.RandomState(12)
+    for thr in (0.5, 1.0 / 3.0, 0.3, 0.7, 0.45):
+        thr32 = float(np.float32(thr))
+        dets = []
+        for _ in range(400):
+            w, h = rs.randint(8, 200), rs.randint(8, 200)
+            # shift so that inter/union is close to thr: inter = (w-s)*h, union = (w+s)*h
+            s = int(round(w * (1 - thr) / (1 + thr)))
+            for ds in (-1, 0, 1):
+                x0, y0 = rs.randint(0, 5000) * 300.0, 0.0
+                dets.append([x0, y0, x0 + w - 1, y0 + h - 1, rs.uniform(0.5, 1.0)])
+                dets.append([x0 + s + ds, y0, x0 + s + ds + w - 1, y0 + h - 1, rs.uniform(0.0, 0.5)])
+        dets = np.array(dets, np.float32)
+        dets[:, 4] = (rs.permutation(len(dets)) + 1) / (len(dets) + 1.0)
+        want = oracle_lib.nms(dets, thr32)
+        got = ops.nms_indices(torch.from_numpy(dets).cuda(), thr32).cpu().numpy()
+        assert np.array_equal(got, want), thr
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 127, 1025, 4693, 8192])
+def test_nms_op_sizes(ops, oracle_lib, n):
+    rs = np.random.RandomState(n)
+    x1, y1 = rs.uniform(0, 600, n), rs.uniform(0, 600, n)
+    dets = np.stack([x1, y1, x1 + rs.uniform(4, 150, n), y1 + rs.uniform(4, 150, n),
+                     rs.randint(0, max(2, n // 3), n) / float(n)], 1).astype(np.float32)  # score ties
+    got = ops.nms_indices(torch.from_numpy(dets).cuda(), 0.5).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.nms(dets, 0.5))
+
+
+def test_nms_op_empty_and_limits(ops):
+    from iouaware import _lib
+    assert ops.nms_indices(torch.zeros(0, 5).cuda(), 0.5).numel() == 0
+    with pytest.raises(_lib.IouAwareLibraryError):
+        ops.nms_indices(torch.zeros(8193, 5).cuda(), 0.5)
+
+
+# ------------------------------------------------------------------ full size, batch 8
+def test_full_size_batch8_properties(ops, oracle_lib):
+    """BASELINE config 2 geometry (batch 8 at 800x1344).  Size-independent properties:
+    batch invariance (image b of the batch == the same image alone), score order, NMS
+    postcondition, and image 0 against the oracle."""
+    ph, pw, B = 800, 1344, 8
+    geom, base = G.geometry(ph, pw, 1000)
+    metas = [synth.img_meta(800, 1333, ph, pw, 1.0) for _ in range(B)]
+    shapes, sfs = [m['img_shape'] for m in metas], [1.0] * B
+    cls, reg, iou = synth.head_outputs(2024, B, ph, pw, 'C')
+    dc, dr, di = G.to_dev(cls), G.to_dev(reg), G.to_dev(iou)
+    dets, labels, rows, num = [t.cpu().numpy() for t in
+                               ops.get_bboxes(geom, dc, dr, di, shapes, sfs, True, 0.05, 0.5, 100)]
+    for b in (0, 3, 7):
+        one = [t.cpu().numpy() for t in ops.get_bboxes(
+            geom, [x[b:b + 1] for x in dc], [x[b:b + 1] for x in dr], [x[b:b + 1] for x in di],
+            shapes[:1], sfs[:1], True, 0.05, 0.5, 100)]
+        assert int(one[3][0]) == int(num[b])
+        assert np.array_equal(one[0][0], dets[b]) and np.array_equal(one[2][0], rows[b])
+    o = oracle_image(oracle_lib, cls, reg, iou, 0, base, (800, 1333), 1.0, True, 1000, 0.05, 0.5,
+                     100)
+    n0 = int(num[0])
+    assert n0 == o['num_det'] and G.same_bits(dets[0, :n0], o['det_bboxes'])
+    assert np.array_equal(rows[0, :n0], o['det_rows'])
+    for b in range(B):
+        n = int(num[b])
+        s = dets[b, :n, 4]
+        assert (s[:-1] >= s[1:]).all() and (s > 0.05).all()
+        # NMS postcondition: same-class survivors overlap < thr
+        for c in np.unique(labels[b, :n]):
+            bb = dets[b, :n][labels[b, :n] == c, :4].astype(np.float32)
+            for i in range(len(bb)):
+                for j in range(i + 1, len(bb)):
+                    xx1, yy1 = max(bb[i, 0], bb[j, 0]), max(bb[i, 1], bb[j, 1])
+                    xx2, yy2 = min(bb[i, 2], bb[j, 2]), min(bb[i, 3], bb[j, 3])
+                    inter = max(0., xx2 - xx1 + 1) * max(0., yy2 - yy1 + 1)
+                    ai = (bb[i, 2] - bb[i, 0] + 1) * (bb[i, 3] - bb[i, 1] + 1)
+                    aj = (bb[j, 2] - bb[j, 0] + 1) * (bb[j, 3] - bb[j, 1] + 1)
+                    assert inter / (ai + aj - inter) < 0.5

@@ -1,0 +1,102 @@
+"""CPU: the oracle (oracle/iouaware_oracle.c) against the golden vectors that
+tests/golden/make_golden.py captured from the imported reference.
+
+Bar: every index bit-exact; floats |a-b| <= 1e-4 * max(1, |b|).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    if a.size == 0:
+        return True
+    return bool((np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))).all())
+
+
+def test_base_and_grid_anchors(oracle_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'anchors.npz'))
+    base = oracle_lib.head_base_anchors(synth.STRIDES)
+    for i, s in enumerate(synth.STRIDES):
+        assert np.array_equal(base[i], g['base_%d' % s])
+    # SURVEY 8a I1 stride-8 literal
+    assert base[0].tolist() == [[-19, -7, 26, 14], [-25, -10, 32, 17], [-32, -14, 39, 21],
+                                [-12, -12, 19, 19], [-16, -16, 23, 23], [-21, -21, 28, 28],
+                                [-7, -19, 14, 26], [-10, -25, 17, 32], [-14, -32, 21, 39]]
+    assert np.array_equal(oracle_lib.grid_anchors(base[0], 5, 7, 8), g['grid_8_5x7'])
+    assert np.array_equal(oracle_lib.grid_anchors(base[2], 3, 4, 32), g['grid_32_3x4'])
+    assert np.array_equal(oracle_lib.gen_base_anchors(16, [8, 16, 32], [0.5, 1, 2]),
+                          g['base_16_rpn'])
+
+
+def test_delta2bbox(oracle_lib, golden_dir):
+    d = np.load(os.path.join(golden_dir, 'delta2bbox.npz'))
+    assert close(oracle_lib.delta2bbox(d['rois'], d['deltas'], max_shape=(800, 1333)),
+                 d['out_clamped'])
+    assert close(oracle_lib.delta2bbox(d['rois'], d['deltas']), d['out_free'])
+    assert close(oracle_lib.delta2bbox(d['rois'], d['deltas'], stds=(0.1, 0.1, 0.2, 0.2),
+                                       max_shape=(800, 1333)), d['out_stds'])
+
+
+def test_nms_cases(oracle_lib, golden_dir):
+    n = np.load(os.path.join(golden_dir, 'nms.npz'))
+    for i in range(int(n['num_cases'])):
+        keep = oracle_lib.nms(n['dets_%d' % i], float(n['thr_%d' % i]))
+        assert np.array_equal(keep, n['keep_%d' % i]), 'case %d' % i
+    # nms_cpu.cpp:55 uses ">=": IoU exactly 1/3 is suppressed at thr=fp32(1/3), kept at 0.34
+    assert oracle_lib.nms(n['edge_dets_0'], float(n['edge_thr_0'])).tolist() == [0]
+    assert oracle_lib.nms(n['edge_dets_1'], float(n['edge_thr_1'])).tolist() == [0, 1]
+    assert np.array_equal(n['edge_keep_0'], [0]) and np.array_equal(n['edge_keep_1'], [0, 1])
+
+
+def test_nms_matches_real_reference_binary(oracle_lib):
+    """oracle/_ref/nms_cpu_ref.so is the reference's own nms_cpu.cpp (travels to the GPU box)."""
+    import build_ref
+    mod = build_ref.load()
+    if mod is None:
+        pytest.skip('oracle/_ref not built')
+    import torch
+    rs = np.random.RandomState(5)
+    for n in (1, 17, 300, 1500):
+        x1, y1 = rs.uniform(0, 400, n), rs.uniform(0, 400, n)
+        dets = np.stack([x1, y1, x1 + rs.uniform(4, 150, n), y1 + rs.uniform(4, 150, n),
+                         rs.permutation(n) / n], 1).astype(np.float32)
+        ref = mod.nms(torch.from_numpy(dets), 0.5).numpy()
+        assert np.array_equal(oracle_lib.nms(dets, 0.5), ref)
+
+
+def run_oracle(oracle_lib, f, b, cls, reg, iou):
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    base = oracle_lib.head_base_anchors(synth.STRIDES)
+    return oracle_lib.get_bboxes_single(
+        [x[b] for x in cls], [x[b] for x in reg], [x[b] for x in iou], synth.STRIDES, base,
+        (ih, iw), float(f['scale_factors'][b]), bool(f['rescale']), int(f['nms_pre']),
+        float(f['score_thr']), float(f['iou_thr']), int(f['max_per_img']))
+
+
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C'])
+def test_get_bboxes(oracle_lib, golden_dir, name):
+    f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    B = int(f['batch'])
+    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    assert synth.checksum(cls + reg + iou) == int(f['checksum']), 'synthetic inputs drifted'
+    for b in range(B):
+        r = run_oracle(oracle_lib, f, b, cls, reg, iou)
+        assert np.array_equal(r['topk_inds'], f['topk_inds_%d' % b])
+        assert np.array_equal(r['keep_count'], f['keep_count_%d' % b])
+        kr = np.concatenate([r['keep_rows'][c, :r['keep_count'][c]] for c in range(synth.C)])
+        assert np.array_equal(kr, f['keep_rows_%d' % b])
+        assert np.array_equal(r['det_labels'], f['det_labels_%d' % b])
+        assert np.array_equal(r['det_rows'], f['det_rows_%d' % b])
+        assert close(r['det_bboxes'], f['det_bboxes_%d' % b])
+        if 'mlvl_bboxes_%d' % b in f:
+            assert close(r['mlvl_bboxes'], f['mlvl_bboxes_%d' % b])
+            assert close(r['mlvl_scores'], f['mlvl_scores_%d' % b])
