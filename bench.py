@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path BASELINE.json names: images/sec at 1333x800,
+IoU-aware RetinaNet R-50-FPN (fp32), batch 8 per GPU on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole inference path over one batch of synthetic
+COCO-shaped input already resident in HBM: ResNet-50 + FPN + head convolutions
+(PyTorch-ROCm / MIOpen) -> HIP row-max / top-k / gather+decode / batched NMS /
+final top-100 -> (N>1) one RCCL all-gather of the per-image detections.
+Weights are random-init (no checkpoints offline), data synthetic; images are
+sharded data-parallel (weak scaling: 8 images per GPU per step).
+
+Prints ONE JSON line (rank 0) with the driver's fields plus
+  roofline     -- the dominant hand-written kernel (k_rowmax, HBM bound): algorithmic bytes
+                  per launch / average launch duration, timed with HIP events on the launch
+                  stream inside the timed steps;
+  cpu_baseline -- the same workload on the host cores (rank 0, N=1 only): PyTorch-CPU
+                  convolutions + the C oracle (oracle/, a port of the reference CPU path) on a
+                  bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import iouaware  # noqa: E402
+from iouaware import ops  # noqa: E402
+from iouaware import dist as idist  # noqa: E402
+from iouaware.config import ConfigDict  # noqa: E402
+
+IMG_H, IMG_W, PAD_H, PAD_W = 800, 1333, 800, 1344
+BATCH = 8
+HEAD_BYTES_PER_IMAGE = 68544000          # cls+reg+iou logits, fp32, read once
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+MODEL = dict(
+    type='RetinaNet', pretrained=None,
+    backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                  frozen_stages=1, style='pytorch'),
+    neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+              add_extra_convs=True, num_outs=5),
+    bbox_head=dict(type='IoUawareRetinaHead', num_classes=81, in_channels=256, stacked_convs=4,
+                   feat_channels=256, octave_base_scale=4, scales_per_octave=3,
+                   anchor_ratios=[0.5, 1.0, 2.0], anchor_strides=[8, 16, 32, 64, 128],
+                   target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0],
+                   loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
+                                 loss_weight=1.0),
+                   loss_bbox=dict(type='SmoothL1Loss', beta=0.11, loss_weight=1.0)))
+TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_thr=0.5),
+                max_per_img=100)
+
+
+def build_model(device):
+    torch.manual_seed(0)
+    model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=None,
+                                    test_cfg=ConfigDict(TEST_CFG))
+    return model.to(device).eval()
+
+
+def metas(batch):
+    return [dict(ori_shape=(IMG_H, IMG_W, 3), img_shape=(IMG_H, IMG_W, 3),
+                 pad_shape=(PAD_H, PAD_W, 3), scale_factor=1.0, flip=False) for _ in range(batch)]
+
+
+class Stepper(object):
+    """one benchmark step, with HIP events around the row-max kernel"""
+
+    def __init__(self, model, imgs, world):
+        self.model, self.imgs, self.world = model, imgs, world
+        self.metas = metas(imgs.shape[0])
+        self.cfg = model.test_cfg
+        self.rowmax_ms = []
+        self.pending = []
+        self.last = None
+
+    @torch.no_grad()
+    def step(self, timed=False):
+        m = self.model
+        cls, reg, iou = m.forward_head(self.imgs)
+        head = m.bbox_head
+        geom = head.geometry([tuple(c.shape[-2:]) for c in cls], self.cfg.get('nms_pre', -1))
+        shapes = [x['img_shape'] for x in self.metas]
+        factors = [x['scale_factor'] for x in self.metas]
+        if timed:
+            # same five kernels as ops.get_bboxes, launched stage by stage so that HIP events
+            # on the launch stream bracket k_rowmax alone
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
+            e1.record()
+            self.pending.append((e0, e1))
+            idx = ops.select_topk(geom, rm)
+            boxes, scores_t = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors, True)
+            dets, labels, rows, num = ops.multiclass_nms(boxes, scores_t, geom.R,
+                                                         self.cfg.score_thr, self.cfg.nms.iou_thr,
+                                                         self.cfg.max_per_img)[:4]
+        else:
+            dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
+                                                     self.cfg.score_thr, self.cfg.nms.iou_thr,
+                                                     self.cfg.max_per_img)
+        if self.world > 1:
+            dets, labels, num = idist.all_gather_detections(dets, labels, num)
+        self.last = (dets, labels, num, cls, reg, iou)
+        return dets
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for e0, e1 in self.pending:
+            self.rowmax_ms.append(e0.elapsed_time(e1))
+        self.pending = []
+
+
+def cpu_baseline(model, stepper):
+    """Same workload on the host cores, bounded sample: ONE image of the batch.
+    convs: PyTorch CPU (all threads); post-conv path: the C oracle (1 thread), which is a
+    port of the reference CPU path pinned against it by tests/golden."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import copy
+    import oracle
+    oracle.build()
+    cpu_model = copy.deepcopy(model).to('cpu').eval()
+    img = stepper.imgs[:1].cpu()
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        cpu_model.forward_head(img[:, :, :64, :64])          # warm the allocator / oneDNN
+        t0 = time.time()
+        cls, reg, iou = cpu_model.forward_head(img)
+        t_conv = time.time() - t0
+    head = cpu_model.bbox_head
+    base = np.stack([g.base_anchors.numpy() for g in head.anchor_generators])
+    t0 = time.time()
+    res = oracle.get_bboxes_single([c[0].numpy() for c in cls], [r[0].numpy() for r in reg],
+                                   [i[0].numpy() for i in iou], head.anchor_strides, base,
+                                   (IMG_H, IMG_W), 1.0, True, TEST_CFG['nms_pre'],
+                                   TEST_CFG['score_thr'], TEST_CFG['nms']['iou_thr'],
+                                   TEST_CFG['max_per_img'])
+    t_post = time.time() - t0
+    total = t_conv + t_post
+    return dict(value=round(1.0 / total, 4), unit='img/s', cores=threads, kind='port',
+                sample='1 image of the batch (3x800x1344): PyTorch-CPU convs %.2f s on %d threads'
+                       ' + C oracle get_bboxes %.2f s on 1 thread (%d boxes into NMS); host has'
+                       ' %d cores' % (t_conv, threads, t_post,
+                                      int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum()),
+                                      os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl')
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
+
+    model = build_model(device)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    imgs = torch.randn(BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
+    stepper = Stepper(model, imgs, world)
+
+    for _ in range(args.warmup):
+        stepper.step(timed=True)
+    stepper.collect()
+    stepper.rowmax_ms = []
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(timed=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stepper.collect()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        n_img = BATCH * world * args.steps
+        ms_rowmax = float(np.mean(stepper.rowmax_ms))
+        achieved = HEAD_BYTES_PER_IMAGE * BATCH / (ms_rowmax * 1e-3) / 1e9
+        out = {
+            'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN',
+            'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': 'IoU-aware RetinaNet R-50-FPN fp32, batch 8 per GPU, '
+                                   '3x800x1344 (1333x800 padded to /32), random-init weights, '
+                                   'whole inference path incl. NMS',
+                       'global_batch': BATCH * world, 'parallelism': 'dp%d' % world,
+                       'dets_per_image': int(stepper.last[2].float().mean().item())},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_rowmax', 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
+                         'avg_launch_ms': round(ms_rowmax, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, stepper)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

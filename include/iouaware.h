@@ -120,7 +120,9 @@ int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *coun
  * the NCHW head outputs directly.  Each *_fwd ADDS one fp64 sum (the
  * numerator the reference divides by avg_factor, losses.py:301-303,411,480)
  * into *loss_sum (device, zeroed by the caller; one fp64 atomic per workgroup);
- * each *_bwd writes gscale * d(sum)/d(input) with the input's NCHW shape.     */
+ * each *_bwd writes s * d(sum)/d(input) with the input's NCHW shape, where
+ * s = gscale (host) * (gscale_dev ? *gscale_dev : 1): the upstream gradient
+ * may stay on the device, so backward never synchronises with the host.       */
 
 /* FocalLoss -> weighted_sigmoid_focal_loss -> py_sigmoid_focal_loss
  * (mmdet/core/loss/losses.py:226-247,279-303) fused with expand_binary_labels
@@ -131,15 +133,16 @@ int ia_focal_loss_fwd(const void *cls, int dtype, const int64_t *labels,
                       float alpha, double *loss_sum, void *stream);
 int ia_focal_loss_bwd(const void *cls, int dtype, const int64_t *labels,
                       const float *label_weights, int B, int A, int C, int HW, float gamma,
-                      float alpha, float gscale, float *grad_cls, void *stream);
+                      float alpha, float gscale, const float *gscale_dev, float *grad_cls,
+                      void *stream);
 
 /* SmoothL1Loss -> weighted_smoothl1 (losses.py:385-411).  pred NCHW
  * (B,A*4,H,W); target / weight (B,N_l,4) row-major.                           */
 int ia_smooth_l1_fwd(const void *pred, int dtype, const float *target, const float *weight,
                      int B, int A, int HW, float beta, double *loss_sum, void *stream);
 int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const float *weight,
-                     int B, int A, int HW, float beta, float gscale, float *grad_pred,
-                     void *stream);
+                     int B, int A, int HW, float beta, float gscale, const float *gscale_dev,
+                     float *grad_pred, void *stream);
 
 /* IoU target (delta2bbox x2 + aligned bbox_overlaps,
  * iou_aware_retina_head.py:256-259, mmdet/core/bbox/geometry.py:34-47) fused
@@ -152,7 +155,8 @@ int ia_iou_bce_fwd(const ia_head_geom *g, int level, const void *bbox_pred, cons
                    float *iou_target, double *loss_sum, void *stream);
 int ia_iou_bce_bwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
                    int dtype, const float *bbox_targets, const float *bbox_weights, int B,
-                   float gscale, float *grad_iou_pred, float *grad_bbox_pred, void *stream);
+                   float gscale, const float *gscale_dev, float *grad_iou_pred,
+                   float *grad_bbox_pred, void *stream);
 
 /* mmdet.ops.sigmoid_focal_loss: sigmoid_focal_loss_cuda.forward / .backward
  * (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-63,65-105;

@@ -42,6 +42,13 @@ __device__ __forceinline__ void block_sum_to(double v, double *dst, double *lds 
     }
 }
 
+// upstream gradient: host scalar times an optional device scalar (autograd's
+// grad_output stays on the device: no host synchronisation in backward)
+__device__ __forceinline__ float eff_scale(float host, const float *dev)
+{
+    return dev ? host * dev[0] : host;
+}
+
 // ------------------------------------------------------------------ focal
 struct FocalArgs {
     const void *cls;
@@ -51,9 +58,10 @@ struct FocalArgs {
     float *grad;
     int32_t B, A, C, HW;
     float gamma, alpha_pos, alpha_neg, gscale;
+    const float *gscale_dev;
 };
 
-__device__ __forceinline__ void focal_elem(float x, bool t, float w0, const FocalArgs &a,
+__device__ __forceinline__ void focal_elem(float x, bool t, float w0, const FocalArgs &a, float gs,
                                            float &loss, float &grad, bool want_grad)
 {
     float pr = sigmoidf_(x);
@@ -73,7 +81,7 @@ __device__ __forceinline__ void focal_elem(float x, bool t, float w0, const Foca
         else if (a.gamma == 0.0f) dmod = 0.0f;
         else dmod = a.gamma * powf_pos_(pt, a.gamma - 1.0f);
         float g = dbce * W + (bce * at) * (dmod * dpt);
-        grad = g * a.gscale;
+        grad = g * gs;
     }
 }
 
@@ -92,6 +100,7 @@ __global__ void __launch_bounds__(1024) k_focal(FocalArgs a)
     float *grad = BWD ? a.grad + ((size_t)b * A + an) * C * HW : nullptr;
     const size_t nbase = (size_t)b * HW * A;
     double acc = 0.0;
+    const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = p0 + lane + 64 * j;
@@ -102,7 +111,7 @@ __global__ void __launch_bounds__(1024) k_focal(FocalArgs a)
         for (int c = 0; c < C; ++c) {
             float x = load_f32<T>(cls + (size_t)c * HW + p);
             float l, g = 0.0f;
-            focal_elem(x, lab == (int64_t)(c + 1), w0, a, l, g, BWD);
+            focal_elem(x, lab == (int64_t)(c + 1), w0, a, gs, l, g, BWD);
             if (BWD) grad[(size_t)c * HW + p] = g;
             else acc += (double)l;
         }
@@ -112,14 +121,15 @@ __global__ void __launch_bounds__(1024) k_focal(FocalArgs a)
 
 static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *labels,
                         const float *lw, int B, int A, int C, int HW, float gamma, float alpha,
-                        float gscale, double *loss_sum, float *grad, hipStream_t s)
+                        float gscale, const float *gscale_dev, double *loss_sum, float *grad,
+                        hipStream_t s)
 {
     if (!cls || !labels || !lw || B < 1 || A < 1 || A > IA_MAX_ANCHORS || C < 1 || HW < 1)
         return IA_E_ARG;
     if (bwd ? !grad : !loss_sum) return IA_E_ARG;
     FocalArgs a;
     a.cls = cls; a.labels = labels; a.label_weights = lw; a.loss_sum = loss_sum; a.grad = grad;
-    a.B = B; a.A = A; a.C = C; a.HW = HW; a.gamma = gamma; a.gscale = gscale;
+    a.B = B; a.A = A; a.C = C; a.HW = HW; a.gamma = gamma; a.gscale = gscale; a.gscale_dev = gscale_dev;
     a.alpha_pos = alpha;
     a.alpha_neg = (float)(1.0 - (double)alpha);   // python: (1 - alpha) in double, then fp32
     dim3 block(64, A), grid((unsigned)(B * ((HW + kLossTile - 1) / kLossTile)));
@@ -142,6 +152,7 @@ struct SmoothArgs {
     float *grad;
     int32_t B, A, HW;
     float beta, gscale;
+    const float *gscale_dev;
 };
 
 template <typename T, bool BWD>
@@ -151,6 +162,7 @@ __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
     const int A = a.A, HW = a.HW;
     const size_t total = (size_t)a.B * A * 4 * HW;
     double acc = 0.0;
+    const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(e % HW);
@@ -166,7 +178,7 @@ __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
         if (BWD) {
             float sgn = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
             float g = (d < a.beta) ? df / a.beta : sgn;
-            a.grad[e] = (g * w) * a.gscale;
+            a.grad[e] = (g * w) * gs;
         } else {
             float l = (d < a.beta) ? ((0.5f * d) * d) / a.beta : d - 0.5f * a.beta;
             acc += (double)(l * w);
@@ -177,13 +189,13 @@ __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
 
 static int launch_smooth(bool bwd, const void *pred, int dtype, const float *target,
                          const float *weight, int B, int A, int HW, float beta, float gscale,
-                         double *loss_sum, float *grad, hipStream_t s)
+                         const float *gscale_dev, double *loss_sum, float *grad, hipStream_t s)
 {
     if (!pred || !target || !weight || B < 1 || A < 1 || HW < 1 || !(beta > 0.0f)) return IA_E_ARG;
     if (bwd ? !grad : !loss_sum) return IA_E_ARG;
     SmoothArgs a;
     a.pred = pred; a.target = target; a.weight = weight; a.loss_sum = loss_sum; a.grad = grad;
-    a.B = B; a.A = A; a.HW = HW; a.beta = beta; a.gscale = gscale;
+    a.B = B; a.A = A; a.HW = HW; a.beta = beta; a.gscale = gscale; a.gscale_dev = gscale_dev;
     size_t total = (size_t)B * A * 4 * HW;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -241,6 +253,7 @@ struct IouBceArgs {
     float means[4], stds[4];
     int32_t B, A, H, W, stride;
     float gscale;
+    const float *gscale_dev;
 };
 
 template <typename T, bool BWD>
@@ -250,6 +263,7 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
     const int A = a.A, W = a.W, HW = a.H * a.W;
     const size_t total = (size_t)a.B * A * HW;
     double acc = 0.0;
+    const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(e % HW);
@@ -285,9 +299,9 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
             if (a.iou_target) a.iou_target[n] = t;
             acc += (double)(bce_logits_(xl, t) * wt);
         } else {
-            if (a.grad_iou_pred) a.grad_iou_pred[e] = ((sigmoidf_(xl) - t) * wt) * a.gscale;
+            if (a.grad_iou_pred) a.grad_iou_pred[e] = ((sigmoidf_(xl) - t) * wt) * gs;
             if (a.grad_bbox_pred) {
-                float gt = ((-xl) * wt) * a.gscale;
+                float gt = ((-xl) * wt) * gs;
                 float inv_un = 1.0f / un;
                 float g_ov = gt * ((un + ov) * inv_un) * inv_un;
                 float g_a2 = gt * (-(ov * inv_un) * inv_un);
@@ -317,8 +331,8 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
 
 static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void *bbox_pred,
                           const void *iou_pred, int dtype, const float *bt, const float *bw, int B,
-                          float gscale, float *iou_target, double *loss_sum, float *g_iou,
-                          float *g_box, hipStream_t s)
+                          float gscale, const float *gscale_dev, float *iou_target,
+                          double *loss_sum, float *g_iou, float *g_box, hipStream_t s)
 {
     if (!g || level < 0 || level >= g->num_levels || !bbox_pred || !iou_pred || !bt || !bw || B < 1)
         return IA_E_ARG;
@@ -332,7 +346,7 @@ static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void
         for (int k = 0; k < 4; ++k) a.base[i][k] = g->base_anchors[level][i][k];
     for (int k = 0; k < 4; ++k) { a.means[k] = g->means[k]; a.stds[k] = g->stds[k]; }
     a.B = B; a.A = g->num_anchors; a.H = g->H[level]; a.W = g->W[level];
-    a.stride = g->stride[level]; a.gscale = gscale;
+    a.stride = g->stride[level]; a.gscale = gscale; a.gscale_dev = gscale_dev;
     size_t total = (size_t)B * a.A * a.H * a.W;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
@@ -417,40 +431,41 @@ int ia_focal_loss_fwd(const void *cls, int dtype, const int64_t *labels, const f
                       int A, int C, int HW, float gamma, float alpha, double *loss_sum, void *stream)
 {
     return ia::launch_focal(false, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, 1.0f,
-                            loss_sum, nullptr, (hipStream_t)stream);
+                            nullptr, loss_sum, nullptr, (hipStream_t)stream);
 }
 int ia_focal_loss_bwd(const void *cls, int dtype, const int64_t *labels, const float *lw, int B,
-                      int A, int C, int HW, float gamma, float alpha, float gscale, float *grad,
-                      void *stream)
+                      int A, int C, int HW, float gamma, float alpha, float gscale,
+                      const float *gscale_dev, float *grad, void *stream)
 {
     return ia::launch_focal(true, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, gscale,
-                            nullptr, grad, (hipStream_t)stream);
+                            gscale_dev, nullptr, grad, (hipStream_t)stream);
 }
 int ia_smooth_l1_fwd(const void *pred, int dtype, const float *target, const float *weight, int B,
                      int A, int HW, float beta, double *loss_sum, void *stream)
 {
-    return ia::launch_smooth(false, pred, dtype, target, weight, B, A, HW, beta, 1.0f, loss_sum,
-                             nullptr, (hipStream_t)stream);
+    return ia::launch_smooth(false, pred, dtype, target, weight, B, A, HW, beta, 1.0f, nullptr,
+                             loss_sum, nullptr, (hipStream_t)stream);
 }
 int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const float *weight, int B,
-                     int A, int HW, float beta, float gscale, float *grad, void *stream)
+                     int A, int HW, float beta, float gscale, const float *gscale_dev, float *grad,
+                     void *stream)
 {
-    return ia::launch_smooth(true, pred, dtype, target, weight, B, A, HW, beta, gscale, nullptr,
-                             grad, (hipStream_t)stream);
+    return ia::launch_smooth(true, pred, dtype, target, weight, B, A, HW, beta, gscale, gscale_dev,
+                             nullptr, grad, (hipStream_t)stream);
 }
 int ia_iou_bce_fwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
                    int dtype, const float *bt, const float *bw, int B, float *iou_target,
                    double *loss_sum, void *stream)
 {
-    return ia::launch_iou_bce(false, g, level, bbox_pred, iou_pred, dtype, bt, bw, B, 1.0f,
+    return ia::launch_iou_bce(false, g, level, bbox_pred, iou_pred, dtype, bt, bw, B, 1.0f, nullptr,
                               iou_target, loss_sum, nullptr, nullptr, (hipStream_t)stream);
 }
 int ia_iou_bce_bwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
-                   int dtype, const float *bt, const float *bw, int B, float gscale, float *g_iou,
-                   float *g_box, void *stream)
+                   int dtype, const float *bt, const float *bw, int B, float gscale,
+                   const float *gscale_dev, float *g_iou, float *g_box, void *stream)
 {
     return ia::launch_iou_bce(true, g, level, bbox_pred, iou_pred, dtype, bt, bw, B, gscale,
-                              nullptr, nullptr, g_iou, g_box, (hipStream_t)stream);
+                              gscale_dev, nullptr, nullptr, g_iou, g_box, (hipStream_t)stream);
 }
 int ia_sigmoid_focal_loss_fwd(const float *logits, const int64_t *targets, int N, int C,
                               float gamma, float alpha, float *losses, void *stream)

@@ -50,11 +50,11 @@ SIGNATURES = {
     'ia_get_bboxes_workspace_layout': (_i, [_G, _i, C.POINTER(_sz * 6)]),
     'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
-    'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
+    'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
-    'ia_smooth_l1_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
+    'ia_smooth_l1_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     'ia_iou_bce_fwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
-    'ia_iou_bce_bwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    'ia_iou_bce_bwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_test_math': (_i, [_i, _vp, _vp, _vp, _i64, _vp]),

@@ -1,0 +1,75 @@
+"""Loss modules the IoU-aware configs name (`FocalLoss`, `SmoothL1Loss`),
+backed by the HIP loss kernels (csrc/loss.hip).
+
+Two call forms:
+  * the reference's module signature on permuted (N, C) tensors
+    (reference mmdet/models/losses/focal_loss.py:23-35, smooth_l1_loss.py:14-18);
+  * `forward_level(...)` on the NCHW head output of one pyramid level, which is
+    what IoUawareRetinaHead.loss_single uses: no permute copy, no (N,80) int64
+    one-hot, no (N,80) expanded weight.
+Both return a (1,)-shaped tensor = loss_weight * sum / avg_factor, like the
+reference's weighted_* functions (losses.py:279-303, 403-411).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import LOSSES
+
+
+@LOSSES.register_module
+class FocalLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, loss_weight=1.0, gamma=2.0, alpha=0.25):
+        super(FocalLoss, self).__init__()
+        if use_sigmoid is not True:
+            raise AssertionError('Only sigmoid focaloss supported now.')
+        self.use_sigmoid, self.loss_weight, self.gamma, self.alpha = \
+            use_sigmoid, loss_weight, gamma, alpha
+
+    def forward_level(self, cls_score, labels, label_weights, num_anchors, avg_factor):
+        """cls_score (B, A*C, H, W); labels (B, N_l) int64 in 0..C; label_weights (B, N_l)."""
+        total = ops.focal_loss_sum(cls_score, labels, label_weights, num_anchors, self.gamma,
+                                   self.alpha)
+        return total * (self.loss_weight / float(avg_factor))
+
+    def forward(self, cls_score, label, label_weight, avg_factor=None, **kwargs):
+        """cls_score (N, C); label (N, C) one-hot or (N,) integer 0..C; label_weight (N, C)
+        row-constant or (N,)."""
+        if cls_score.dim() != 2:
+            raise AssertionError('cls_score must be (N, C)')
+        n, c = cls_score.shape
+        if label.dim() == 2:
+            hot = label > 0
+            label = torch.where(hot.any(1), hot.to(torch.int64).argmax(1) + 1,
+                                torch.zeros(n, dtype=torch.int64, device=label.device))
+        if label_weight.dim() == 2:
+            label_weight = label_weight[:, 0]
+        if avg_factor is None:
+            avg_factor = float((label_weight > 0).sum().item()) + 1e-6
+        # an (N, C) row-major matrix is the NCHW layout with B=N, A=1, HW=1
+        total = ops.focal_loss_sum(cls_score.reshape(n, c, 1, 1), label, label_weight, 1,
+                                   self.gamma, self.alpha)
+        return total * (self.loss_weight / float(avg_factor))
+
+
+@LOSSES.register_module
+class SmoothL1Loss(nn.Module):
+    def __init__(self, beta=1.0, loss_weight=1.0):
+        super(SmoothL1Loss, self).__init__()
+        self.beta, self.loss_weight = beta, loss_weight
+
+    def forward_level(self, bbox_pred, bbox_targets, bbox_weights, num_anchors, avg_factor):
+        """bbox_pred (B, A*4, H, W); targets / weights (B, N_l, 4)."""
+        total = ops.smooth_l1_sum(bbox_pred, bbox_targets, bbox_weights, num_anchors, self.beta)
+        return total * (self.loss_weight / float(avg_factor))
+
+    def forward(self, pred, target, weight, avg_factor=None, **kwargs):
+        """pred / target / weight (N, 4)."""
+        if pred.size() != target.size() or target.numel() == 0:
+            raise AssertionError('pred / target shape mismatch or empty')
+        if avg_factor is None:
+            avg_factor = float((weight > 0).sum().item()) / 4 + 1e-6
+        n = pred.shape[0]
+        total = ops.smooth_l1_sum(pred.reshape(n, 4, 1, 1), target.reshape(n, 1, 4),
+                                  weight.reshape(n, 1, 4), 1, self.beta)
+        return total * (self.loss_weight / float(avg_factor))

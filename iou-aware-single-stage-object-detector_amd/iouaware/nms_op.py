@@ -1,0 +1,65 @@
+"""`mmdet.ops.nms.nms` and `mmdet.core.multiclass_nms` with the reference's
+call signatures, on the HIP kernels (reference mmdet/ops/nms/nms_wrapper.py:8-49,
+mmdet/core/post_processing/bbox_nms.py:6-67)."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def nms(dets, iou_thr, device_id=None):
+    """dets: (n,5) Tensor on a ROCm device, or ndarray + device_id.  Returns (dets[inds], inds)
+    in the input's type; inds ascending (the CPU reference's order, nms_cpu.cpp:58).
+
+    The reference dispatches CPU tensors to its C++ loop; this build has no CPU compute
+    path -- a CPU tensor or an ndarray without device_id raises.
+    """
+    if isinstance(dets, torch.Tensor):
+        is_numpy, dets_th = False, dets
+    elif isinstance(dets, np.ndarray):
+        is_numpy = True
+        if device_id is None:
+            raise ops._lib.IouAwareLibraryError(
+                'nms on a numpy array needs device_id: there is no CPU NMS in this build')
+        dets_th = torch.from_numpy(dets).to('cuda:{}'.format(device_id))
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
+            type(dets)))
+    if dets_th.shape[0] == 0:
+        inds = dets_th.new_zeros(0, dtype=torch.long)
+    else:
+        inds = ops.nms_indices(dets_th, iou_thr)
+    if is_numpy:
+        inds = inds.cpu().numpy()
+    return dets[inds, :], inds
+
+
+def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    raise NotImplementedError('soft_nms is not on the IoU-aware configs\' path (test_cfg uses '
+                              "type='nms'); SURVEY 8f lists it as next")
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
+                   score_factors=None):
+    """multi_bboxes (n,4), multi_scores (n,C+1) with the background column first.
+    -> (bboxes (k,5), labels (k,) int64).  One batched launch for all classes."""
+    if multi_bboxes.shape[1] != 4:
+        raise NotImplementedError('class-specific boxes (n, C*4) are a two-stage feature')
+    if score_factors is not None:
+        raise NotImplementedError('score_factors is unused on this path')
+    cfg = dict(nms_cfg)
+    if cfg.pop('type', 'nms') != 'nms':
+        raise NotImplementedError('only hard nms is built')
+    n = multi_bboxes.shape[0]
+    if n == 0:
+        return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
+    if max_num is None or max_num < 0:
+        max_num = ops._lib.IA_MAX_PER_IMG
+    Cn = multi_scores.shape[1] - 1
+    Rs = (n + 63) // 64 * 64
+    scores_t = multi_bboxes.new_zeros((1, Cn, Rs), dtype=torch.float32)
+    scores_t[0, :, :n] = multi_scores[:, 1:].t().to(torch.float32)
+    out = ops.multiclass_nms(multi_bboxes.to(torch.float32).reshape(1, n, 4), scores_t, n,
+                             score_thr, cfg['iou_thr'], int(max_num))
+    k = int(out[3][0].item())
+    return out[0][0, :k], out[1][0, :k].to(torch.long)

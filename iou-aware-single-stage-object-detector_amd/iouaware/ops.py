@@ -242,6 +242,11 @@ def test_math(op, x, y=None):
 
 
 # ----------------------------------------------------------------- training losses
+def _gdev(g):
+    """autograd's grad_output as a 1-element fp32 device tensor (no host sync)"""
+    return g.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+
+
 class _FocalLossFn(torch.autograd.Function):
     """sum over the level of py_sigmoid_focal_loss on NCHW logits."""
 
@@ -268,7 +273,7 @@ class _FocalLossFn(torch.autograd.Function):
         B, ch, H, W = cls.shape
         grad = torch.empty(cls.shape, dtype=torch.float32, device=cls.device)
         _lib.check(_lib.lib().ia_focal_loss_bwd(_ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw),
-                                                B, A, Cn, H * W, gamma, alpha, float(g.item()),
+                                                B, A, Cn, H * W, gamma, alpha, 1.0, _ptr(_gdev(g)),
                                                 _ptr(grad), _stream()), 'ia_focal_loss_bwd')
         return grad.to(cls.dtype), None, None, None, None, None
 
@@ -300,7 +305,7 @@ class _SmoothL1Fn(torch.autograd.Function):
         B, ch, H, W = pred.shape
         grad = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
         _lib.check(_lib.lib().ia_smooth_l1_bwd(_ptr(pred), _dtype_code(pred), _ptr(target),
-                                               _ptr(weight), B, A, H * W, beta, float(g.item()),
+                                               _ptr(weight), B, A, H * W, beta, 1.0, _ptr(_gdev(g)),
                                                _ptr(grad), _stream()), 'ia_smooth_l1_bwd')
         return grad.to(pred.dtype), None, None, None, None
 
@@ -338,8 +343,8 @@ class _IouBceFn(torch.autograd.Function):
                             device=bbox_pred.device) if attach else None
         _lib.check(_lib.lib().ia_iou_bce_bwd(geom.ref(), level, _ptr(bbox_pred), _ptr(iou_pred),
                                              _dtype_code(bbox_pred), _ptr(bt), _ptr(bw), B,
-                                             float(g.item()), _ptr(g_iou), _ptr(g_box), _stream()),
-                   'ia_iou_bce_bwd')
+                                             1.0, _ptr(_gdev(g)), _ptr(g_iou), _ptr(g_box),
+                                             _stream()), 'ia_iou_bce_bwd')
         return (g_box.to(bbox_pred.dtype) if attach else None, g_iou.to(iou_pred.dtype), None,
                 None, None, None, None)
 

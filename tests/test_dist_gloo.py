@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the N>1 result exchange.  Each rank owns
+the images rank, rank+W, ... (DistributedSampler order); one all_gather of
+fixed-size records returns all detections in dataset order on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+PKG = os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_dets(i, M=100):
+    """deterministic per-image detections"""
+    rs = np.random.RandomState(1000 + i)
+    k = int(rs.randint(0, M + 1))
+    dets = np.zeros((M, 5), np.float32)
+    dets[:k] = rs.uniform(0, 1000, (k, 5)).astype(np.float32)
+    labels = np.full(M, -1, np.int32)
+    labels[:k] = rs.randint(0, 80, k)
+    return dets, labels, k
+
+
+def _worker(rank, world, port, num_samples, ret):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from iouaware import dist as idist
+    r, w = idist.init_dist('pytorch', backend='gloo')
+    assert (r, w) == (rank, world) and idist.get_dist_info() == (rank, world)
+    mine = idist.shard_indices(num_samples, rank, world)
+    d, l, n = zip(*[_fake_dets(i) for i in mine])
+    dets = torch.from_numpy(np.stack(d))
+    labels = torch.from_numpy(np.stack(l))
+    num = torch.tensor(n, dtype=torch.int32)
+    D, L, N = idist.all_gather_detections(dets, labels, num, num_samples=num_samples)
+    ok = D.shape[0] == num_samples
+    for i in range(num_samples):
+        ed, el, ek = _fake_dets(i)
+        ok &= bool(np.array_equal(D[i].numpy(), ed) and np.array_equal(L[i].numpy(), el)
+                   and int(N[i]) == ek)
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_wrap_around():
+    sys.path.insert(0, PKG)
+    from iouaware import dist as idist
+    assert idist.shard_indices(5, 0, 2) == [0, 2, 4]
+    assert idist.shard_indices(5, 1, 2) == [1, 3, 0]        # padded by wrap-around
+    assert idist.shard_indices(8, 3, 8) == [3]
+
+
+def test_all_gather_detections_world2_gloo():
+    world, num_samples = 2, 5
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, num_samples, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_pack_unpack_roundtrip():
+    sys.path.insert(0, PKG)
+    from iouaware import dist as idist
+    d, l, k = zip(*[_fake_dets(i, 7) for i in range(3)])
+    dets, labels = torch.from_numpy(np.stack(d)), torch.from_numpy(np.stack(l))
+    num = torch.tensor(k, dtype=torch.int32)
+    D, L, N = idist.unpack_detections(idist.pack_detections(dets, labels, num), 7)
+    assert torch.equal(D, dets) and torch.equal(L, labels) and torch.equal(N, num)
