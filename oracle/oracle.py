@@ -155,3 +155,68 @@ def get_bboxes_single(cls, reg, iou, strides, base_anchors, img_shape, scale_fac
 
 def sigmoid_nonmonotone_count(lo, hi):
     return int(lib().ia_o_count_sigmoid_nonmonotone(C.c_float(lo), C.c_float(hi)))
+
+
+# ------------------------------------------------------------------ training losses
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def focal_loss(cls, labels, label_weights, A, gamma=2.0, alpha=0.25, gscale=None):
+    """cls (B, A*C, H, W); labels (B*N_l) int64; label_weights (B*N_l).
+    -> (sum, grad or None); grad = gscale * d sum / d cls."""
+    cls = _f(cls)
+    B, ch, H, W = cls.shape
+    Cn = ch // A
+    labels = np.ascontiguousarray(labels, np.int64).reshape(-1)
+    lw = _f(label_weights).reshape(-1)
+    grad = np.empty_like(cls) if gscale is not None else None
+    s = lib().ia_o_focal_loss(_fp(cls), _i64p(labels), _fp(lw), B, A, Cn, H * W, C.c_float(gamma),
+                              C.c_float(alpha), C.c_float(np.float32(1.0 - alpha)),
+                              C.c_float(0.0 if gscale is None else gscale),
+                              _fp(grad) if grad is not None else None)
+    return s, grad
+
+
+def smooth_l1(pred, target, weight, A, beta, gscale=None):
+    pred = _f(pred)
+    B, ch, H, W = pred.shape
+    target, weight = _f(target), _f(weight)
+    grad = np.empty_like(pred) if gscale is not None else None
+    s = lib().ia_o_smooth_l1(_fp(pred), _fp(target), _fp(weight), B, A, H * W, C.c_float(beta),
+                             C.c_float(0.0 if gscale is None else gscale),
+                             _fp(grad) if grad is not None else None)
+    return s, grad
+
+
+def iou_bce(bbox_pred, iou_pred, bbox_targets, bbox_weights, base, stride, means=(0, 0, 0, 0),
+            stds=(1, 1, 1, 1), gscale=None, attach=True):
+    """-> (sum, iou_target (B*N_l), grad_iou_pred, grad_bbox_pred)"""
+    bbox_pred, iou_pred = _f(bbox_pred), _f(iou_pred)
+    B, A, H, W = iou_pred.shape
+    bt, bw, base = _f(bbox_targets), _f(bbox_weights), _f(base)
+    means, stds = _f(means), _f(stds)
+    tgt = np.empty(B * A * H * W, np.float32)
+    g_iou = np.empty_like(iou_pred) if gscale is not None else None
+    g_box = np.empty_like(bbox_pred) if (gscale is not None and attach) else None
+    s = lib().ia_o_iou_bce(_fp(bbox_pred), _fp(iou_pred), _fp(bt), _fp(bw), _fp(base), B, A, H, W,
+                           int(stride), _fp(means), _fp(stds),
+                           C.c_float(0.0 if gscale is None else gscale), _fp(tgt),
+                           _fp(g_iou) if g_iou is not None else None,
+                           _fp(g_box) if g_box is not None else None)
+    return s, tgt, g_iou, g_box
+
+
+def focal_loss_op(logits, targets, gamma, alpha, d_losses=None):
+    logits = _f(logits)
+    N, Cn = logits.shape
+    targets = np.ascontiguousarray(targets, np.int64)
+    out = np.empty_like(logits)
+    if d_losses is None:
+        lib().ia_o_focal_loss_op_fwd(_fp(logits), _i64p(targets), N, Cn, C.c_float(gamma),
+                                     C.c_float(alpha), _fp(out))
+    else:
+        d = _f(d_losses)
+        lib().ia_o_focal_loss_op_bwd(_fp(logits), _i64p(targets), _fp(d), N, Cn, C.c_float(gamma),
+                                     C.c_float(alpha), _fp(out))
+    return out

@@ -1,0 +1,171 @@
+"""GPU (MI355X): the HIP loss kernels (csrc/loss.hip) through the C-ABI / the
+autograd wrappers, against the CPU oracle (elementwise gradients BIT-EXACT, sums
+within 1e-6 relative: the reduction order differs) and against the reference's
+own losses / autograd gradients in tests/golden/losses_small.npz (1e-4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available()
+    from iouaware import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
+def fx(golden_dir):
+    f = np.load(os.path.join(golden_dir, 'losses_small.npz'))
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    B = int(f['batch'])
+    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    return f, cls, reg, iou, B, (ph, pw)
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-12)
+
+
+def test_focal_smoothl1_ioubce_vs_oracle_and_reference(ops, oracle_lib, fx):
+    f, cls, reg, iou, B, (ph, pw) = fx
+    geom, base = G.geometry(ph, pw, -1)
+    avg = float(f['num_total_pos'])
+    gs = np.float32(1.0 / avg)
+    for l, (h, w) in enumerate(geom.featmap_sizes):
+        n_l = h * w * synth.A
+        labels = torch.from_numpy(f['labels_%d' % l]).cuda()
+        lw = torch.from_numpy(f['label_weights_%d' % l]).cuda()
+        bt = torch.from_numpy(f['bbox_targets_%d' % l]).cuda().reshape(B, n_l, 4)
+        bw = torch.from_numpy(f['bbox_weights_%d' % l]).cuda().reshape(B, n_l, 4)
+        c = torch.from_numpy(cls[l]).cuda().requires_grad_(True)
+        r = torch.from_numpy(reg[l]).cuda().requires_grad_(True)
+        i = torch.from_numpy(iou[l]).cuda().requires_grad_(True)
+        # the loss exactly as the head composes it: sum * (loss_weight / avg_factor)
+        lc = ops.focal_loss_sum(c, labels, lw, synth.A, 2.0, 0.25) * float(gs)
+        lb = ops.smooth_l1_sum(r, bt, bw, synth.A, 0.11) * float(gs)
+        li = ops.iou_bce_sum(r, i, bt, bw, geom, l, True) * float(gs)
+        (lc + lb + li).sum().backward()
+        torch.cuda.synchronize()
+        # --- vs oracle
+        so, go = oracle_lib.focal_loss(cls[l], f['labels_%d' % l], f['label_weights_%d' % l],
+                                       synth.A, 2.0, 0.25, gscale=float(gs))
+        assert rel(float(lc) / float(gs), so) < 1e-6
+        assert G.same_bits(c.grad.cpu().numpy(), go), 'focal grad level %d' % l
+        so, go = oracle_lib.smooth_l1(reg[l], f['bbox_targets_%d' % l], f['bbox_weights_%d' % l],
+                                      synth.A, 0.11, gscale=float(gs))
+        assert abs(float(lb) / float(gs) - so) <= 1e-6 * max(abs(so), 1e-6)
+        so2, tgt, g_iou, g_box = oracle_lib.iou_bce(reg[l], iou[l], f['bbox_targets_%d' % l],
+                                                    f['bbox_weights_%d' % l], base[l],
+                                                    synth.STRIDES[l], gscale=float(gs))
+        assert abs(float(li) / float(gs) - so2) <= 1e-6 * max(abs(so2), 1e-6)
+        assert G.same_bits(i.grad.cpu().numpy(), g_iou), 'iou grad level %d' % l
+        # bbox_pred grad = smooth-L1 part + IoU-target part, summed by autograd in fp32
+        assert G.same_bits(r.grad.cpu().numpy(), go + g_box), 'reg grad level %d' % l
+        t_dev, _ = ops.iou_targets(r.detach(), i.detach(), bt, bw, geom, l)
+        assert G.same_bits(t_dev.cpu().numpy(), tgt)
+        # --- vs the reference (golden)
+        assert rel(float(lc), f['loss_cls'][l]) < 1e-4
+        assert abs(float(lb) - f['loss_bbox'][l]) <= 1e-4 * max(f['loss_bbox'][l], 1e-6)
+        assert abs(float(li) - f['losses_iou'][l]) <= 1e-4 * max(f['losses_iou'][l], 1e-6)
+        for key, g, mode, tol in (('g_cls_%d' % l, c.grad, 'attached', 1e-4),
+                                  ('g_iou_%d' % l, i.grad, 'attached', 1e-4),
+                                  ('g_reg_%d' % l, r.grad, 'attached', 2e-4)):
+            idx = f[key + '_idx']
+            want = f['%s_%s' % (key, mode)].astype(np.float64)
+            got = g.cpu().numpy().reshape(-1)[idx].astype(np.float64)
+            assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30), key
+
+
+def test_detached_iou_target_variant(ops, oracle_lib, fx):
+    f, cls, reg, iou, B, (ph, pw) = fx
+    geom, base = G.geometry(ph, pw, -1)
+    l = 0
+    h, w = geom.featmap_sizes[l]
+    n_l = h * w * synth.A
+    bt = torch.from_numpy(f['bbox_targets_%d' % l]).cuda().reshape(B, n_l, 4)
+    bw = torch.from_numpy(f['bbox_weights_%d' % l]).cuda().reshape(B, n_l, 4)
+    r = torch.from_numpy(reg[l]).cuda().requires_grad_(True)
+    i = torch.from_numpy(iou[l]).cuda().requires_grad_(True)
+    ops.iou_bce_sum(r, i, bt, bw, geom, l, False).sum().backward()
+    assert r.grad is None and i.grad is not None
+
+
+def test_head_loss_end_to_end_vs_reference(ops, fx):
+    """IoUawareRetinaHead.loss (targets in torch on the GPU + HIP losses) reproduces the
+    reference's loss dict for the same head outputs and gt boxes."""
+    from iouaware.config import ConfigDict
+    from iouaware.head import IoUawareRetinaHead
+    from test_host_targets import HEAD_KW, TRAIN_CFG
+    f, cls, reg, iou, B, (ph, pw) = fx
+    ih, iw = int(f['img'][0]), int(f['img'][1])
+    head = IoUawareRetinaHead(**HEAD_KW).cuda()
+    metas = [synth.img_meta(ih, iw, ph, pw) for _ in range(B)]
+    gts = [torch.from_numpy(f['gt_bboxes_%d' % b]).cuda() for b in range(B)]
+    gls = [torch.from_numpy(f['gt_labels_%d' % b]).cuda() for b in range(B)]
+    c = [t.requires_grad_(True) for t in G.to_dev(cls)]
+    r = [t.requires_grad_(True) for t in G.to_dev(reg)]
+    i = [t.requires_grad_(True) for t in G.to_dev(iou)]
+    losses = head.loss(c, r, i, gts, gls, metas, TRAIN_CFG)
+    assert sorted(losses) == ['loss_bbox', 'loss_cls', 'losses_iou']     # key spelled as :387
+    for k in losses:
+        got = np.array([float(x) for x in losses[k]])
+        assert all(x.shape == (1,) for x in losses[k])
+        assert np.all(np.abs(got - f[k]) <= 1e-4 * np.maximum(np.abs(f[k]), 1e-6)), k
+    sum(sum(v) for v in losses.values()).backward()
+    for l in range(5):
+        for key, g in (('g_cls_%d' % l, c[l].grad), ('g_reg_%d' % l, r[l].grad),
+                       ('g_iou_%d' % l, i[l].grad)):
+            idx = f[key + '_idx']
+            want = f[key + '_attached'].astype(np.float64)
+            got = g.cpu().numpy().reshape(-1)[idx].astype(np.float64)
+            assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), key
+
+
+def test_sigmoid_focal_loss_op(ops, oracle_lib):
+    """mmdet.ops.sigmoid_focal_loss semantics (integer targets, elementwise), bit-exact vs oracle."""
+    from iouaware.focal_op import sigmoid_focal_loss, SigmoidFocalLoss
+    rs = np.random.RandomState(4)
+    N, Cn = 3000, 80
+    x = (rs.standard_normal((N, Cn)) * 4).astype(np.float32)
+    t = rs.randint(-1, Cn + 1, N).astype(np.int64)
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    td = torch.from_numpy(t).cuda()
+    out = sigmoid_focal_loss(xd, td, 2.0, 0.25, 'none')
+    assert G.same_bits(out.detach().cpu().numpy(), oracle_lib.focal_loss_op(x, t, 2.0, 0.25))
+    dl = rs.uniform(0.5, 1.5, (N, Cn)).astype(np.float32)
+    out.backward(torch.from_numpy(dl).cuda())
+    assert G.same_bits(xd.grad.cpu().numpy(), oracle_lib.focal_loss_op(x, t, 2.0, 0.25, dl))
+    m = SigmoidFocalLoss(2.0, 0.25)
+    # the reference module reduces with the function's default 'mean' (modules/...:17-19)
+    assert abs(float(m(xd.detach(), td)) - float(out.mean())) <= 1e-4 * abs(float(out.mean()))
+    with pytest.raises(AssertionError):
+        m(xd.detach().cpu(), td.cpu())
+
+
+def test_loss_module_signatures_on_permuted_inputs(ops, oracle_lib, fx):
+    """FocalLoss / SmoothL1Loss called the reference way: (N,C) scores, one-hot labels,
+    expanded weights (focal_loss.py:23-35, smooth_l1_loss.py:14-18)."""
+    from iouaware.losses import FocalLoss, SmoothL1Loss
+    from iouaware.targets import expand_binary_labels
+    f, cls, reg, iou, B, (ph, pw) = fx
+    l = 2
+    labels = torch.from_numpy(f['labels_%d' % l]).reshape(-1).cuda()
+    lw = torch.from_numpy(f['label_weights_%d' % l]).reshape(-1).cuda()
+    onehot, wexp = expand_binary_labels(labels, lw, 80)
+    score = torch.from_numpy(cls[l]).cuda().permute(0, 2, 3, 1).reshape(-1, 80)
+    avg = float(f['num_total_pos'])
+    got = FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25)(score, onehot, wexp, avg_factor=avg)
+    assert got.shape == (1,) and rel(float(got), f['loss_cls'][l]) < 1e-4
+    pred = torch.from_numpy(reg[0]).cuda().permute(0, 2, 3, 1).reshape(-1, 4)
+    bt = torch.from_numpy(f['bbox_targets_0']).cuda().reshape(-1, 4)
+    bw = torch.from_numpy(f['bbox_weights_0']).cuda().reshape(-1, 4)
+    got = SmoothL1Loss(beta=0.11)(pred, bt, bw, avg_factor=avg)
+    assert abs(float(got) - f['loss_bbox'][0]) <= 1e-4 * f['loss_bbox'][0]
