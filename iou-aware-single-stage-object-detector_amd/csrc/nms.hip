@@ -35,12 +35,13 @@ namespace ia {
 
 constexpr int kNmsThreads = 1024;
 constexpr int kNmsWaves = kNmsThreads / kWave;
-constexpr int kOwn = IA_MAX_CANDIDATES / kNmsThreads;   // sorted positions owned per thread
+constexpr int kMaxOwn = IA_MAX_CANDIDATES / kNmsThreads;   // sorted positions owned per thread (max)
 
 struct IouThr {
     double mid;      // midpoint between thr and its fp32 predecessor
     float thr;
     int32_t inclusive;
+    int32_t is_half; // thr == 0.5f: fl(inter/uni) >= 0.5  <=>  2*inter >= uni, exact in fp32
 };
 
 static IouThr make_thr(float thr)
@@ -51,6 +52,7 @@ static IouThr make_thr(float thr)
     t.mid = ((double)pred + (double)thr) * 0.5;
     uint32_t bits = __builtin_bit_cast(uint32_t, thr);
     t.inclusive = (bits & 1u) == 0u;
+    t.is_half = (thr == 0.5f);
     return t;
 }
 
@@ -68,10 +70,20 @@ __device__ __forceinline__ bool suppresses(float sx1, float sy1, float sx2, floa
     float inter = w * h;
     float uni = (sarea + carea) - inter;
     if (uni > 0.0f) {
+        // thr = 0.5 (every reference config): q = inter/uni rounds to >= 0.5 iff q >= 0.5 - 2^-26,
+        // and no two fp32 numbers 2*inter < uni are closer than 2^-24 * uni, so the test is the
+        // exact fp32 comparison 2*inter >= uni (2*inter is exact).
+        if (t.is_half) return (inter + inter) >= uni;
         double lhs = (double)inter, rhs = t.mid * (double)uni;
         return t.inclusive ? (lhs >= rhs) : (lhs > rhs);
     }
     return (inter / uni) >= t.thr;
+}
+
+// value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float bcast(float v, int src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
 struct NmsSmem {
@@ -89,7 +101,7 @@ struct NmsSmem {
 //   Score    row -> float
 //   Box      row -> float4
 // keep_out receives the kept rows ascending; returns the count (all threads).
-template <class Pred, class Score, class Box>
+template <int kOwn, class Pred, class Score, class Box>
 __device__ uint32_t nms_block(uint32_t R, Pred pred, Score score, Box box, const IouThr &thr,
                               int32_t *keep_out, NmsSmem &sm, uint64_t *keys)
 {
@@ -159,8 +171,8 @@ __device__ uint32_t nms_block(uint32_t R, Pred pred, Score score, Box box, const
                 const int src = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 if (!((amask >> src) & 1ull)) continue;
-                float sx1 = __shfl(bx1, src), sy1 = __shfl(by1, src);
-                float sx2 = __shfl(bx2, src), sy2 = __shfl(by2, src), sar = __shfl(bar, src);
+                float sx1 = bcast(bx1, src), sy1 = bcast(by1, src);
+                float sx2 = bcast(bx2, src), sy2 = bcast(by2, src), sar = bcast(bar, src);
                 bool sup = (lane > src) && ((amask >> lane) & 1ull) &&
                            suppresses(sx1, sy1, sx2, sy2, sar, bx1, by1, bx2, by2, bar, thr);
                 amask &= ~__ballot(sup);
@@ -227,6 +239,7 @@ struct NmsArgs {
     int32_t R, Rs, C;
 };
 
+template <int kOwn>
 __global__ void __launch_bounds__(kNmsThreads) k_nms_class(NmsArgs a)
 {
     extern __shared__ uint64_t keys[];
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__(kNmsThreads) k_nms_class(NmsArgs a)
     const float *sc = a.scores_t + ((size_t)b * a.C + c) * a.Rs;
     const float4 *bx = reinterpret_cast<const float4 *>(a.boxes) + (size_t)b * a.R;
     const float st = a.score_thr;
-    uint32_t cnt = nms_block((uint32_t)a.R,
+    uint32_t cnt = nms_block<kOwn>((uint32_t)a.R,
                              [sc, st](uint32_t r) { return sc[r] > st; },      // bbox_nms.py:34
                              [sc](uint32_t r) { return sc[r]; },
                              [bx](uint32_t r) { return bx[r]; }, a.thr,
@@ -255,10 +268,21 @@ int launch_nms(const float *boxes, const float *scores_t, int batch, int R, int 
     uint32_t P = 2;
     while (P < (uint32_t)R) P <<= 1;
     size_t lds = sizeof(uint64_t) * P;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_nms_class),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_nms_class, dim3((unsigned)C, (unsigned)batch), dim3(kNmsThreads), lds, s, a);
+    const dim3 grid((unsigned)C, (unsigned)batch), block(kNmsThreads);
+#define IA_LAUNCH_NMS(OWN)                                                                        \
+    do {                                                                                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_nms_class<OWN>),      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(k_nms_class<OWN>, grid, block, lds, s, a);                             \
+    } while (0)
+    const int own = (R + kNmsThreads - 1) / kNmsThreads;    // registers follow the real row count
+    if (own <= 1) IA_LAUNCH_NMS(1);
+    else if (own <= 2) IA_LAUNCH_NMS(2);
+    else if (own <= 3) IA_LAUNCH_NMS(3);
+    else if (own <= 5) IA_LAUNCH_NMS(5);
+    else IA_LAUNCH_NMS(kMaxOwn);
+#undef IA_LAUNCH_NMS
     return hip_status(hipGetLastError());
 }
 
@@ -276,7 +300,7 @@ __global__ void __launch_bounds__(kNmsThreads) k_nms_single(NmsSingleArgs a)
     extern __shared__ uint64_t keys[];
     __shared__ NmsSmem sm;
     const float *d = a.dets;
-    uint32_t cnt = nms_block((uint32_t)a.n, [](uint32_t) { return true; },
+    uint32_t cnt = nms_block<kMaxOwn>((uint32_t)a.n, [](uint32_t) { return true; },
                              [d](uint32_t r) { return d[5 * (size_t)r + 4]; },
                              [d](uint32_t r) {
                                  const float *q = d + 5 * (size_t)r;
