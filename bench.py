@@ -61,11 +61,15 @@ TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nm
                 max_per_img=100)
 
 
-def build_model(device):
+def build_model(device, fuse=True):
     torch.manual_seed(0)
     model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=None,
                                     test_cfg=ConfigDict(TEST_CFG))
-    return model.to(device).eval()
+    model = model.to(device).eval()
+    if fuse:
+        from iouaware.fuse import fuse_inference
+        fuse_inference(model)       # conv epilogues (BN / bias / add / ReLU) -> one HIP pass each
+    return model
 
 
 def metas(batch):
@@ -129,7 +133,7 @@ def cpu_baseline(model, stepper):
     import copy
     import oracle
     oracle.build()
-    cpu_model = copy.deepcopy(model).to('cpu').eval()
+    cpu_model = copy.deepcopy(model).to('cpu').eval()   # fused forwards fall back on CPU tensors
     img = stepper.imgs[:1].cpu()
     threads = torch.get_num_threads()
     with torch.no_grad():
@@ -161,6 +165,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -175,7 +180,7 @@ def main():
         dist.init_process_group(backend='nccl')
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
 
-    model = build_model(device)
+    model = build_model(device, fuse=not args.no_fuse)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     imgs = torch.randn(BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
     stepper = Stepper(model, imgs, world)

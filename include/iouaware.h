@@ -168,6 +168,17 @@ int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const
                               int N, int C, float gamma, float alpha, float *d_logits,
                               void *stream);
 
+/* ------------------------------------------------------------------ conv epilogues
+ * In place on an NCHW tensor x (N, C, HW contiguous):
+ *   x = act(x * scale[c] + shift[c] [+ residual * res_scale[c] + res_shift[c]]).
+ * Any of scale / shift / res_scale / res_shift may be NULL (1 / 0).  Fuses the
+ * eval-mode BatchNorm -> (+identity) -> ReLU chains of the reference Bottleneck
+ * (mmdet/models/backbones/resnet.py:215-255) and ConvModule's bias -> ReLU
+ * (mmdet/models/utils/conv_module.py:149-163) into one pass per convolution.   */
+int ia_channel_affine_act(void *x, int dtype, const float *scale, const float *shift,
+                          const void *residual, const float *res_scale, const float *res_shift,
+                          int relu, int N, int C, int64_t HW, void *stream);
+
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the
  * device implementation bit-for-bit: op 0 exp, 1 log, 2 sigmoid, 3 sqrt,

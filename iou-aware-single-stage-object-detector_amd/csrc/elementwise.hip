@@ -1,0 +1,138 @@
+// Fused per-channel affine (+ residual) (+ ReLU), in place on an NCHW tensor:
+//
+//     x[n,c,:] = act( x[n,c,:] * scale[c] + shift[c]  [+ r[n,c,:] * rscale[c] + rshift[c]] )
+//
+// Inference-time replacement for the eval-mode BatchNorm -> (add) -> ReLU chains
+// around the MIOpen convolutions (reference ResNet Bottleneck forward,
+// mmdet/models/backbones/resnet.py:215-255; ConvModule conv+bias -> relu,
+// mmdet/models/utils/conv_module.py:149-163).  PyTorch eager runs each of those
+// as its own full read+write pass over the activation; one pass here does BN3 +
+// downsample-BN + residual add + ReLU.  Pure HBM streaming: 16 B per lane,
+// one (n,c) plane chunk per workgroup so scale/shift are wave-uniform scalars.
+#include "ia_internal.hpp"
+#include "ia_math.hpp"
+
+namespace ia {
+
+struct AffineArgs {
+    void *x;
+    const void *res;
+    const float *scale, *shift, *rscale, *rshift;
+    int64_t HW;
+    int32_t C, relu;
+};
+
+constexpr int kEwThreads = 256;
+constexpr int kEwPerThread = 16;      // elements per thread per workgroup (4 x 16 B for fp32)
+
+template <typename T> struct Pack;
+template <> struct Pack<float> {
+    static constexpr int N = 4;
+    using V = float4;
+    static __device__ __forceinline__ void unpack(const V &q, float (&v)[4]) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    static __device__ __forceinline__ V pack(const float (&v)[4]) { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Pack<uint16_t> {
+    static constexpr int N = 8;
+    using V = uint4;
+    static __device__ __forceinline__ void unpack(const V &q, float (&v)[8])
+    {
+        v[0] = from_bits(q.x << 16); v[1] = from_bits(q.x & 0xffff0000u);
+        v[2] = from_bits(q.y << 16); v[3] = from_bits(q.y & 0xffff0000u);
+        v[4] = from_bits(q.z << 16); v[5] = from_bits(q.z & 0xffff0000u);
+        v[6] = from_bits(q.w << 16); v[7] = from_bits(q.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint32_t rne(float f)       // fp32 -> bf16 bits, round-nearest-even
+    {
+        uint32_t u = to_bits(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    static __device__ __forceinline__ V pack(const float (&v)[8])
+    {
+        V q;
+        q.x = rne(v[0]) | (rne(v[1]) << 16); q.y = rne(v[2]) | (rne(v[3]) << 16);
+        q.z = rne(v[4]) | (rne(v[5]) << 16); q.w = rne(v[6]) | (rne(v[7]) << 16);
+        return q;
+    }
+};
+
+template <typename T> __device__ __forceinline__ void store_f32(T *p, float v);
+template <> __device__ __forceinline__ void store_f32<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_f32<uint16_t>(uint16_t *p, float v) { *p = (uint16_t)Pack<uint16_t>::rne(v); }
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kEwThreads) k_affine_act(AffineArgs a)
+{
+    const int plane = blockIdx.x;                 // n * C + c
+    const int c = plane % a.C;
+    const float sc = a.scale ? a.scale[c] : 1.0f;
+    const float sh = a.shift ? a.shift[c] : 0.0f;
+    const bool has_res = a.res != nullptr;
+    const float rs = (has_res && a.rscale) ? a.rscale[c] : 1.0f;
+    const float rb = (has_res && a.rshift) ? a.rshift[c] : 0.0f;
+    T *x = static_cast<T *>(a.x) + (size_t)plane * a.HW;
+    const T *r = has_res ? static_cast<const T *>(a.res) + (size_t)plane * a.HW : nullptr;
+    constexpr int N = Pack<T>::N;
+    const int64_t base = (int64_t)blockIdx.y * kEwThreads * kEwPerThread;
+    if (VEC) {
+        using V = typename Pack<T>::V;
+#pragma unroll
+        for (int u = 0; u < kEwPerThread / N; ++u) {
+            const int64_t i = base + ((int64_t)u * kEwThreads + threadIdx.x) * N;
+            if (i < a.HW) {
+                float v[N], w[N];
+                Pack<T>::unpack(*reinterpret_cast<const V *>(x + i), v);
+                if (has_res) Pack<T>::unpack(*reinterpret_cast<const V *>(r + i), w);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float y = v[j] * sc + sh;
+                    if (has_res) y = y + (w[j] * rs + rb);
+                    v[j] = (a.relu && !(y > 0.0f)) ? ((y != y) ? y : 0.0f) : y;
+                }
+                *reinterpret_cast<V *>(x + i) = Pack<T>::pack(v);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int u = 0; u < kEwPerThread; ++u) {
+            const int64_t i = base + (int64_t)u * kEwThreads + threadIdx.x;
+            if (i < a.HW) {
+                float y = load_f32<T>(x + i) * sc + sh;
+                if (has_res) y = y + (load_f32<T>(r + i) * rs + rb);
+                y = (a.relu && !(y > 0.0f)) ? ((y != y) ? y : 0.0f) : y;
+                store_f32<T>(x + i, y);
+            }
+        }
+    }
+}
+
+}  // namespace ia
+
+extern "C" int ia_channel_affine_act(void *x, int dtype, const float *scale, const float *shift,
+                                     const void *residual, const float *res_scale,
+                                     const float *res_shift, int relu, int N, int C, int64_t HW,
+                                     void *stream)
+{
+    if (!x || N < 1 || C < 1 || HW < 1 || (int64_t)N * C > 2147483647LL) return IA_E_ARG;
+    ia::AffineArgs a;
+    a.x = x; a.res = residual; a.scale = scale; a.shift = shift; a.rscale = res_scale;
+    a.rshift = res_shift; a.HW = HW; a.C = C; a.relu = relu;
+    const int64_t per_block = (int64_t)ia::kEwThreads * ia::kEwPerThread;
+    const int64_t chunks = (HW + per_block - 1) / per_block;
+    if (chunks > 65535) return IA_E_ARG;
+    dim3 grid((unsigned)(N * C), (unsigned)chunks);
+    hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == IA_F32 ? 4 : 2;
+    const int n = 16 / esz;
+    const bool vec = (HW % n == 0) && (((uintptr_t)x & 15u) == 0) &&
+                     (!residual || ((uintptr_t)residual & 15u) == 0);
+    if (dtype == IA_F32) {
+        if (vec) hipLaunchKernelGGL((ia::k_affine_act<float, true>), grid, dim3(ia::kEwThreads), 0, s, a);
+        else hipLaunchKernelGGL((ia::k_affine_act<float, false>), grid, dim3(ia::kEwThreads), 0, s, a);
+    } else if (dtype == IA_BF16) {
+        if (vec) hipLaunchKernelGGL((ia::k_affine_act<uint16_t, true>), grid, dim3(ia::kEwThreads), 0, s, a);
+        else hipLaunchKernelGGL((ia::k_affine_act<uint16_t, false>), grid, dim3(ia::kEwThreads), 0, s, a);
+    } else return IA_E_ARG;
+    return ia::hip_status(hipGetLastError());
+}

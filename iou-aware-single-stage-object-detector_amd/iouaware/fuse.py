@@ -1,0 +1,154 @@
+"""Inference-time fusion of the elementwise chains around the convolutions.
+
+`fuse_inference(model)` switches ResNet/ResNeXt blocks, the stem and every
+ConvModule to a forward that runs  conv (MIOpen)  ->  ONE HIP epilogue kernel
+(csrc/elementwise.hip: per-channel affine [+ residual affine] [+ ReLU], in
+place) instead of PyTorch eager's BatchNorm, add and ReLU kernels, each of
+which is a full read+write pass over the activation:
+
+    Bottleneck (reference resnet.py:215-255):  bn1,relu | bn2,relu | bn3,(bn_d),add,relu
+                                               7-8 passes  ->  3 passes
+    ConvModule (conv_module.py:149-163):       bias add, relu  ->  1 pass
+
+Parameters and state_dict are untouched (checkpoints still load); the folded
+per-channel scale/shift are recomputed from the BatchNorm buffers by
+`fuse_inference`, so call it AFTER loading weights.  Only eval-mode, no-grad,
+GPU forwards take the fused route; anything else falls back to the module's
+ordinary forward.  BatchNorm in eval mode is y = (x-mean)/sqrt(var+eps)*g + b;
+the folded form x*scale+shift differs from it by rounding only.
+"""
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import ops
+from .backbones import BasicBlock, Bottleneck, ResNet
+from .layers import ConvModule
+
+
+def _fold_bn(bn):
+    if not isinstance(bn, _BatchNorm):
+        raise TypeError('only BatchNorm can be folded, got %s' % type(bn).__name__)
+    with torch.no_grad():
+        var, mean = bn.running_var.float(), bn.running_mean.float()
+        g = bn.weight.float() if bn.weight is not None else torch.ones_like(var)
+        b = bn.bias.float() if bn.bias is not None else torch.zeros_like(var)
+        scale = g / torch.sqrt(var + bn.eps)
+        shift = b - mean * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _fast(module, x):
+    return (not module.training) and (not torch.is_grad_enabled()) and x.is_cuda \
+        and x.dtype in (torch.float32, torch.bfloat16)
+
+
+def _conv_nobias(conv, x):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _bottleneck_forward(self, x):
+    if not _fast(self, x):
+        return type(self).forward(self, x)
+    f = self._ia_fused
+    out = ops.channel_affine_act_(self.conv1(x), f['s1'], f['b1'], relu=True)
+    out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
+    out = self.conv3(out)
+    if self.downsample is None:
+        return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True)
+    idn = self.downsample[0](x)
+    return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=idn, res_scale=f['sd'],
+                                   res_shift=f['bd'], relu=True)
+
+
+def _basic_forward(self, x):
+    if not _fast(self, x):
+        return type(self).forward(self, x)
+    f = self._ia_fused
+    out = ops.channel_affine_act_(self.conv1(x), f['s1'], f['b1'], relu=True)
+    out = self.conv2(out)
+    if self.downsample is None:
+        return ops.channel_affine_act_(out, f['s2'], f['b2'], residual=x, relu=True)
+    idn = self.downsample[0](x)
+    return ops.channel_affine_act_(out, f['s2'], f['b2'], residual=idn, res_scale=f['sd'],
+                                   res_shift=f['bd'], relu=True)
+
+
+def _resnet_forward(self, x):
+    if not _fast(self, x):
+        return type(self).forward(self, x)
+    f = self._ia_fused
+    x = self.maxpool(ops.channel_affine_act_(self.conv1(x), f['s'], f['b'], relu=True))
+    outs = []
+    for i, name in enumerate(self.res_layers):
+        x = getattr(self, name)(x)
+        if i in self.out_indices:
+            outs.append(x)
+    return tuple(outs)
+
+
+def _convmodule_forward(self, x, activate=True, norm=True):
+    if not (_fast(self, x) and self.activate_last):
+        return type(self).forward(self, x, activate, norm)
+    f = self._ia_fused
+    relu = bool(activate and self.with_activatation)
+    if self.with_norm and norm:
+        y = self.conv(x)                      # conv before a norm has no bias
+        return ops.channel_affine_act_(y, f['s'], f['b'], relu=relu)
+    if self.conv.bias is None:
+        y = self.conv(x)
+        return ops.channel_affine_act_(y, None, None, relu=True) if relu else y
+    return ops.channel_affine_act_(_conv_nobias(self.conv, x), None, f['bias'], relu=relu)
+
+
+def fuse_inference(model):
+    """Patch `model` in place (see module docstring).  Returns the number of fused modules."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Bottleneck):
+            f = {}
+            f['s1'], f['b1'] = _fold_bn(m.norm1)
+            f['s2'], f['b2'] = _fold_bn(m.norm2)
+            f['s3'], f['b3'] = _fold_bn(m.norm3)
+            if m.downsample is not None:
+                f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+            m._ia_fused = f
+            m.forward = types.MethodType(_bottleneck_forward, m)
+        elif isinstance(m, BasicBlock):
+            f = {}
+            f['s1'], f['b1'] = _fold_bn(m.norm1)
+            f['s2'], f['b2'] = _fold_bn(m.norm2)
+            if m.downsample is not None:
+                f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+            m._ia_fused = f
+            m.forward = types.MethodType(_basic_forward, m)
+        elif isinstance(m, ResNet):
+            f = {}
+            f['s'], f['b'] = _fold_bn(m.norm1)
+            m._ia_fused = f
+            m.forward = types.MethodType(_resnet_forward, m)
+        elif isinstance(m, ConvModule):
+            f = {}
+            if m.with_norm:
+                if not isinstance(m.norm, _BatchNorm):
+                    continue                   # GroupNorm etc.: leave eager
+                f['s'], f['b'] = _fold_bn(m.norm)
+            elif m.conv.bias is not None:
+                f['bias'] = m.conv.bias.detach().float().contiguous()
+            m._ia_fused = f
+            m.forward = types.MethodType(_convmodule_forward, m)
+        else:
+            continue
+        n += 1
+    return n
+
+
+def unfuse_inference(model):
+    for m in model.modules():
+        if hasattr(m, '_ia_fused'):
+            del m._ia_fused
+            if 'forward' in m.__dict__:
+                del m.__dict__['forward']

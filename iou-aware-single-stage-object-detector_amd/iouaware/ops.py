@@ -232,6 +232,24 @@ def nms_indices(dets, iou_thr):
     return keep[:m].to(torch.long)
 
 
+def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None, res_shift=None,
+                        relu=False):
+    """In place on a contiguous NCHW tensor: x = act(x*scale[c] + shift[c] [+ residual affine])."""
+    _require_gpu(x, 'x')
+    if not x.is_contiguous():
+        raise ValueError('channel_affine_act_ needs a contiguous NCHW tensor')
+    N, Cn = x.shape[0], x.shape[1]
+    hw = x.numel() // (N * Cn)
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError('residual must match x')
+        residual = residual.contiguous()
+    _lib.check(_lib.lib().ia_channel_affine_act(
+        _ptr(x), _dtype_code(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(res_scale),
+        _ptr(res_shift), int(bool(relu)), N, Cn, hw, _stream()), 'ia_channel_affine_act')
+    return x
+
+
 def test_math(op, x, y=None):
     _require_gpu(x, 'x')
     x = x.contiguous()

@@ -1,0 +1,71 @@
+"""GPU: the conv-epilogue kernel (csrc/elementwise.hip) against plain torch, and the fused
+inference forward against the unfused model (same weights)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 37, 53), (3, 16, 8, 12), (1, 7, 1, 1), (2, 256, 100, 168)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_channel_affine_act_matches_torch(shape, dtype):
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(shape, device='cuda', generator=g).to(dtype)
+    r = torch.randn(shape, device='cuda', generator=g).to(dtype)
+    C = shape[1]
+    s, b, rs, rb = [torch.randn(C, device='cuda', generator=g) for _ in range(4)]
+    v = lambda t: t.view(1, C, 1, 1)          # noqa: E731
+    xf, rf = x.float(), r.float()
+    for relu in (False, True):
+        want = xf * v(s) + v(b)
+        got = ops.channel_affine_act_(x.clone(), s, b, relu=relu).float()
+        w = want.clamp(min=0) if relu else want
+        assert torch.equal(got, w.to(dtype).float())
+        want = (xf * v(s) + v(b)) + (rf * v(rs) + v(rb))
+        got = ops.channel_affine_act_(x.clone(), s, b, residual=r, res_scale=rs, res_shift=rb,
+                                      relu=relu).float()
+        w = want.clamp(min=0) if relu else want
+        assert torch.equal(got, w.to(dtype).float())
+        got = ops.channel_affine_act_(x.clone(), None, b, residual=r, relu=relu).float()
+        want = (xf * 1.0 + v(b)) + rf
+        w = want.clamp(min=0) if relu else want
+        assert torch.equal(got, w.to(dtype).float())
+
+
+@pytest.mark.parametrize('backbone', [dict(), dict(type='ResNeXt', depth=50, groups=32, base_width=4)])
+def test_fused_inference_matches_unfused(backbone):
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    import bench
+    cfg = ConfigDict(bench.MODEL)
+    cfg.backbone.update(backbone)
+    torch.manual_seed(0)
+    m = iouaware.build_detector(cfg, test_cfg=ConfigDict(bench.TEST_CFG)).cuda().eval()
+    with torch.no_grad():           # make BN statistics / residual branches non-trivial
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.1)
+    x = torch.randn(2, 3, 224, 288, device='cuda')
+    with torch.no_grad():
+        ref = m.forward_head(x)
+        assert fuse_inference(m) >= 33
+        out = m.forward_head(x)
+        unfuse_inference(m)
+        again = m.forward_head(x)
+    for a, b, c in zip(ref, out, again):
+        for u, v, w in zip(a, b, c):
+            scale = float(u.abs().max())
+            assert float((u - v).abs().max()) <= 2e-4 * max(scale, 1.0)
+            # (MIOpen may pick different conv algorithms between calls: no bit-equality here)
+            assert float((u - w).abs().max()) <= 2e-4 * max(scale, 1.0)
+    # training / grad mode keeps the ordinary path
+    fuse_inference(m)
+    m.train()
+    y = m.forward_head(x)
+    assert y[0][0].requires_grad
