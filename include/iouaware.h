@@ -72,7 +72,9 @@ const char *ia_version(void);
  * (mmdet/core/post_processing/bbox_nms.py:6-67).                             */
 
 /* iou_aware_retina_head.py:502-531,539: per anchor max over classes of
- * sqrt(sigmoid(cls)) * sqrt(sigmoid(iou)).  rowmax: (B, N) fp32.             */
+ * sqrt(sigmoid(cls)) * sqrt(sigmoid(iou)).  rowmax: (B, N) fp32; inside an image
+ * each level is an (A, H*W) block (anchor-major), i.e. element a*HW + p holds the
+ * reference's anchor index p*A + a.                                            */
 int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                           float *rowmax, void *stream);
 

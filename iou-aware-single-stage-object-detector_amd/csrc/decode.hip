@@ -14,8 +14,10 @@
 // global load instruction is a contiguous 1 KiB segment, 16 B per lane.
 // Measured on MI355X (tools/ubench/rowmax_variants.hip): single-wavefront
 // workgroups with the tile index fastest stream at 5.4 TB/s, more than
-// 9-wavefront workgroups with an LDS transpose of the output (4.7 TB/s); the
-// 4-byte output stores at stride A are 1.2 % of the traffic and merge in L2.
+// 9-wavefront workgroups with an LDS transpose of the output (4.7 TB/s).  The
+// row-max array is stored anchor-major per level ((A, HW) blocks) so each lane
+// writes consecutive floats: stride-A stores showed 6.6x write amplification in
+// WRITE_SIZE (42.5 MB vs 6.45 MB per batch-8 launch).
 // sqrt(sigmoid(.)) is monotone non-decreasing in
 // fp32 (exhaustively checked by tests/test_oracle_math.py), so the max over
 // classes is taken on the raw logits and the transcendental part runs once
@@ -86,7 +88,8 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
     const int p0 = (rem - an * tiles) * TILE;
     const T *cls = static_cast<const T *>(a.p.cls[l]) + ((size_t)b * A + an) * C * HW;
     const T *iou = static_cast<const T *>(a.p.iou[l]) + ((size_t)b * A + an) * HW;
-    float *out = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l] + an;
+    // row-max array: per level an (A, HW) block, anchor-major -> contiguous, full-line stores
+    float *out = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l] + (size_t)an * HW;
 
     const float ninf = -__builtin_inff();
     float m[PPL], il[PPL];
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
     }
 #pragma unroll
     for (int j = 0; j < PPL; ++j)
-        if (pos[j] < HW) out[(size_t)pos[j] * A] = sqrt_sigmoidf_(m[j]) * sqrt_sigmoidf_(il[j]);
+        if (pos[j] < HW) out[pos[j]] = sqrt_sigmoidf_(m[j]) * sqrt_sigmoidf_(il[j]);
 }
 
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,

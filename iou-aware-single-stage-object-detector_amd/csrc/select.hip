@@ -37,8 +37,11 @@ __global__ void __launch_bounds__(kSelectThreads) k_select(SelectArgs a)
         return;
     }
     const float *src = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
-    auto key = [src](uint32_t i) -> uint64_t {
-        return ((uint64_t)ordered_key(src[i]) << 32) | (uint64_t)(0xffffffffu - i);
+    // storage order is anchor-major (a, p); the reference's anchor index is p*A + a
+    const uint32_t HW = (uint32_t)(a.t.H[l] * a.t.W[l]), A = (uint32_t)a.t.A;
+    auto key = [src, HW, A](uint32_t i) -> uint64_t {
+        const uint32_t an = i / HW, p = i - an * HW;
+        return ((uint64_t)ordered_key(src[i]) << 32) | (uint64_t)(0xffffffffu - (p * A + an));
     };
     block_topk_desc(key, n, k, sc, sel);
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x)

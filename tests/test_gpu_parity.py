@@ -75,7 +75,13 @@ def check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, resc
     for b in range(B):
         o = oracle_image(oracle_lib, cls, reg, iou, b, base, shapes[b][:2], sfs[b], rescale,
                          geom.struct.nms_pre, score_thr, iou_thr, max_per_img, means, stds)
-        assert G.same_bits(dbg['rowmax'][b], o['rowmax']), 'rowmax img %d' % b
+        # device layout: per level an (A, HW) block; oracle: reference order p*A + a
+        off = 0
+        for (h, w) in geom.featmap_sizes:
+            n_l = h * w * geom.A
+            dev = dbg['rowmax'][b][off:off + n_l].reshape(geom.A, h * w).T.reshape(-1)
+            assert G.same_bits(dev, o['rowmax'][off:off + n_l]), 'rowmax img %d' % b
+            off += n_l
         assert np.array_equal(dbg['cand_idx'][b], o['topk_inds']), 'topk img %d' % b
         assert G.same_bits(dbg['boxes'][b], o['mlvl_bboxes']), 'boxes img %d' % b
         assert G.same_bits(dbg['scores_t'][b][:, :geom.R].T, o['mlvl_scores']), 'scores img %d' % b
