@@ -105,10 +105,11 @@ class Stepper(object):
             e1.record()
             self.pending.append((e0, e1))
             idx = ops.select_topk(geom, rm)
-            boxes, scores_t = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors, True)
+            boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors,
+                                                      True)
             dets, labels, rows, num = ops.multiclass_nms(boxes, scores_t, geom.R,
                                                          self.cfg.score_thr, self.cfg.nms.iou_thr,
-                                                         self.cfg.max_per_img)[:4]
+                                                         self.cfg.max_per_img, best_score=best)[:4]
         else:
             dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
                                                      self.cfg.score_thr, self.cfg.nms.iou_thr,

@@ -86,20 +86,25 @@ int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_
 /* iou_aware_retina_head.py:545-558 + mmdet/core/bbox/transforms.py:44-78
  * (delta2bbox) + anchor_generator.py:53-70 (anchors regenerated, never read).
  * img_hw: (B,2) fp32 (img_shape h,w); scale_factor: (B,4) fp32.
- * boxes: (B,R,4) fp32; scores_t: (B,C,Rs) fp32 class-major fused scores.      */
+ * boxes: (B,R,4) fp32; scores_t: (B,C,Rs) fp32 class-major fused scores;
+ * best_score: (B,R) fp32 max over classes per candidate (optional, may be NULL).*/
 int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                      const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
-                     int rescale, float *boxes, float *scores_t, void *stream);
+                     int rescale, float *boxes, float *scores_t, float *best_score, void *stream);
 
 /* bbox_nms.py:33-56 + mmdet/ops/nms/src/nms_cpu.cpp:4-59 (greedy, ">=",
  * ascending kept indices), all (image, class) problems in one launch, then the
  * per-image top max_per_img.  Outputs: dets (B,max_per_img,5) fp32, labels and
  * rows (B,max_per_img) int32 (row = candidate row id), num (B) int32,
- * keep_count (B,C) int32, keep_rows (B,C,Rs) int32 ascending.                 */
-int ia_multiclass_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
-                      float score_thr, float iou_thr, int max_per_img, float *dets,
-                      int32_t *labels, int32_t *rows, int32_t *num, int32_t *keep_count,
-                      int32_t *keep_rows, void *stream);
+ * keep_count (B,C) int32, keep_rows (B,C,Rs) int32 ascending.  best_score (B,R)
+ * optional: rows with best_score <= score_thr are skipped when the per-image
+ * suppression bit matrix (the workspace) is built.                             */
+size_t ia_multiclass_nms_workspace_bytes(int batch, int R, int C);
+int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *best_score,
+                      int batch, int R, int C, float score_thr, float iou_thr, int max_per_img,
+                      void *workspace, size_t workspace_bytes, float *dets, int32_t *labels,
+                      int32_t *rows, int32_t *num, int32_t *keep_count, int32_t *keep_rows,
+                      void *stream);
 
 /* Whole path in one call (what the Python head calls).                        */
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
@@ -109,13 +114,17 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
                   float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream);
 
 /* Workspace carve-up of ia_get_bboxes (host helper for stage-level tests):
- * byte offsets of rowmax, cand_idx, boxes, scores_t, keep_count, keep_rows.   */
-int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[6]);
+ * byte offsets of rowmax, cand_idx, boxes, scores_t, keep_count, keep_rows,
+ * best_score, NMS stage workspace (bit matrix, sorted rows, counts).          */
+int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[8]);
 
 /* mmdet.ops.nms.nms (mmdet/ops/nms/nms_wrapper.py:8-49 -> nms_cpu.nms /
  * nms_cuda.nms): dets (n,5) fp32 on device, n <= IA_MAX_CANDIDATES.
- * keep (n) int32 ascending input indices, count (1) int32.                    */
-int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *stream);
+ * keep (n) int32 ascending input indices, count (1) int32; workspace holds the
+ * n x n suppression bit matrix.                                               */
+size_t ia_nms_workspace_bytes(int n);
+int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
+           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on

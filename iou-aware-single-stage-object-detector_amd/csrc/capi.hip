@@ -14,7 +14,7 @@ static void base_from_geom(const ia_head_geom *g, BaseAnchors &ba)
     memcpy(ba.v, g->base_anchors, sizeof(ba.v));
 }
 
-struct WsLayout { size_t off[6]; size_t total; int32_t N, R, Rs; };
+struct WsLayout { size_t off[8]; size_t total; int32_t N, R, Rs; };
 
 static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
 {
@@ -34,6 +34,9 @@ static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
     w.off[3] = o; o = align_up(o + B * C * w.Rs * sizeof(float), 256);       // scores_t
     w.off[4] = o; o = align_up(o + B * C * sizeof(int32_t), 256);            // keep_count
     w.off[5] = o; o = align_up(o + B * C * w.Rs * sizeof(int32_t), 256);     // keep_rows
+    w.off[6] = o; o = align_up(o + B * w.R * sizeof(float), 256);            // best_score
+    size_t noff[3];
+    w.off[7] = o; o = align_up(o + nms_workspace_bytes(batch, w.R, t.C, noff), 256);   // NMS stage
     w.total = o;
     return 0;
 }
@@ -93,7 +96,7 @@ int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_
 
 int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                      const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
-                     int rescale, float *boxes, float *scores_t, void *stream)
+                     int rescale, float *boxes, float *scores_t, float *best_score, void *stream)
 {
     ia::WsLayout w;
     int rc = ia::ws_layout(g, batch, w);
@@ -104,17 +107,29 @@ int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, i
     ia::BaseAnchors ba;
     ia::base_from_geom(g, ba);
     return ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand_idx, img_hw,
-                             scale_factor, rescale, boxes, scores_t, w.Rs, (hipStream_t)stream);
+                             scale_factor, rescale, boxes, scores_t, best_score, w.Rs,
+                             (hipStream_t)stream);
 }
 
-int ia_multiclass_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
-                      float score_thr, float iou_thr, int max_per_img, float *dets,
-                      int32_t *labels, int32_t *rows, int32_t *num, int32_t *keep_count,
-                      int32_t *keep_rows, void *stream)
+size_t ia_multiclass_nms_workspace_bytes(int batch, int R, int C)
+{
+    if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1) return 0;
+    size_t off[3];
+    return ia::nms_workspace_bytes(batch, R, C, off);
+}
+
+int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *best_score,
+                      int batch, int R, int C, float score_thr, float iou_thr, int max_per_img,
+                      void *workspace, size_t workspace_bytes, float *dets, int32_t *labels,
+                      int32_t *rows, int32_t *num, int32_t *keep_count, int32_t *keep_rows,
+                      void *stream)
 {
     const int Rs = (R + 63) / 64 * 64;
-    int rc = ia::launch_nms(boxes, scores_t, batch, R, Rs, C, score_thr, iou_thr, keep_count,
-                            keep_rows, (hipStream_t)stream);
+    if (!workspace) return IA_E_ARG;
+    if (workspace_bytes < ia_multiclass_nms_workspace_bytes(batch, R, C) || workspace_bytes == 0)
+        return IA_E_WORKSPACE;
+    int rc = ia::launch_nms(boxes, scores_t, best_score, batch, R, Rs, C, score_thr, iou_thr,
+                            workspace, keep_count, keep_rows, (hipStream_t)stream);
     if (rc) return rc;
     return ia::launch_finalize(boxes, scores_t, keep_count, keep_rows, batch, R, Rs, C,
                                max_per_img, dets, labels, rows, num, (hipStream_t)stream);
@@ -127,12 +142,12 @@ size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch)
     return w.total;
 }
 
-int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[6])
+int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[8])
 {
     ia::WsLayout w;
     int rc = ia::ws_layout(g, batch, w);
     if (rc) return rc;
-    for (int i = 0; i < 6; ++i) offsets[i] = w.off[i];
+    for (int i = 0; i < 8; ++i) offsets[i] = w.off[i];
     return 0;
 }
 
@@ -154,6 +169,8 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
     float *scores_t = reinterpret_cast<float *>(ws + w.off[3]);
     int32_t *kc = reinterpret_cast<int32_t *>(ws + w.off[4]);
     int32_t *kr = reinterpret_cast<int32_t *>(ws + w.off[5]);
+    float *best = reinterpret_cast<float *>(ws + w.off[6]);
+    void *nms_ws = ws + w.off[7];
     hipStream_t s = (hipStream_t)stream;
     ia::LevelTable t;
     ia::make_level_table(g, t);
@@ -162,17 +179,22 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
     if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s))) return rc;
     if ((rc = ia::launch_select(t, rowmax, batch, cand, s))) return rc;
     if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
-                                scale_factor, rescale, boxes, scores_t, w.Rs, s)))
+                                scale_factor, rescale, boxes, scores_t, best, w.Rs, s)))
         return rc;
-    if ((rc = ia::launch_nms(boxes, scores_t, batch, w.R, w.Rs, t.C, score_thr, iou_thr, kc, kr, s)))
+    if ((rc = ia::launch_nms(boxes, scores_t, best, batch, w.R, w.Rs, t.C, score_thr, iou_thr,
+                             nms_ws, kc, kr, s)))
         return rc;
     return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, dets,
                                labels, rows, num, s);
 }
 
-int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *stream)
+size_t ia_nms_workspace_bytes(int n) { return ia::nms_single_workspace_bytes(n); }
+
+int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
+           size_t workspace_bytes, void *stream)
 {
-    return ia::launch_nms_single(dets, n, iou_thr, keep, count, (hipStream_t)stream);
+    return ia::launch_nms_single(dets, n, iou_thr, keep, count, workspace, workspace_bytes,
+                                 (hipStream_t)stream);
 }
 
 int ia_test_math(int op, const float *x, const float *y, float *out, int64_t n, void *stream)

@@ -168,6 +168,7 @@ struct GatherArgs {
     const float *scale_factor;
     float *boxes;
     float *scores_t;
+    float *best_score;       // (B, R) max over classes of the fused score (NMS activity filter)
     int32_t R, Rs, rescale;
 };
 
@@ -176,10 +177,12 @@ constexpr int kGroups = 4;   // class groups per candidate (threadIdx.y)
 template <typename T>
 __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
 {
+    __shared__ float gmax[kGroups][64];
     const int lane = threadIdx.x, grp = threadIdx.y;
     const int b = blockIdx.y;
-    const int r = blockIdx.x * 64 + lane;
-    if (r >= a.R) return;
+    const int r_raw = blockIdx.x * 64 + lane;
+    const bool live = r_raw < a.R;
+    const int r = live ? r_raw : a.R - 1;        // clamp: every thread reaches the barrier
     const int A = a.t.A, C = a.t.C;
     int l = 0;
     while (r >= a.t.cand_off[l + 1]) ++l;
@@ -193,12 +196,22 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
     const int c0 = grp * cpg;
     const int c1 = (c0 + cpg < C) ? (c0 + cpg) : C;
     float *so = a.scores_t + (size_t)b * C * a.Rs + r;
+    float best = 0.0f;                           // scores are >= 0
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
         float x = load_f32<T>(cls + (size_t)c * HW);
-        so[(size_t)c * a.Rs] = sqrt_sigmoidf_(x) * sq_iou;
+        float sc = sqrt_sigmoidf_(x) * sq_iou;
+        if (live) so[(size_t)c * a.Rs] = sc;
+        best = (best < sc) ? sc : best;
     }
-    if (grp == 0) {
+    gmax[grp][lane] = best;
+    __syncthreads();
+    if (grp == 0 && live) {
+        if (a.best_score) {
+#pragma unroll
+            for (int g2 = 1; g2 < kGroups; ++g2) best = (best < gmax[g2][lane]) ? gmax[g2][lane] : best;
+            a.best_score[(size_t)b * a.R + r] = best;
+        }
         const T *reg = static_cast<const T *>(a.p.reg[l]) + ((size_t)b * A + an) * 4 * HW + pos;
         const int y = pos / W, x = pos - y * W;
         const float sx = (float)(x * a.t.stride[l]), sy = (float)(y * a.t.stride[l]);
@@ -240,7 +253,7 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,
-                  float *scores_t, int Rs, hipStream_t s)
+                  float *scores_t, float *best_score, int Rs, hipStream_t s)
 {
     if (batch < 1 || !cand_idx || !img_hw || !boxes || !scores_t) return IA_E_ARG;
     if (rescale && !scale_factor) return IA_E_ARG;
@@ -248,7 +261,7 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
     a.t = t; a.ba = ba; a.p = p;
     for (int i = 0; i < 4; ++i) { a.means[i] = means[i]; a.stds[i] = stds[i]; }
     a.cand_idx = cand_idx; a.img_hw = img_hw; a.scale_factor = scale_factor;
-    a.boxes = boxes; a.scores_t = scores_t;
+    a.boxes = boxes; a.scores_t = scores_t; a.best_score = best_score;
     a.R = t.cand_off[t.num_levels]; a.Rs = Rs; a.rescale = rescale;
     dim3 block(64, kGroups);
     dim3 grid((unsigned)((a.R + 63) / 64), (unsigned)batch);

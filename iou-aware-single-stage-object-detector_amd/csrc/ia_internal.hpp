@@ -49,15 +49,18 @@ int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,
-                  float *scores_t, int Rs, hipStream_t s);
-int launch_nms(const float *boxes, const float *scores_t, int batch, int R, int Rs, int C,
-               float score_thr, float iou_thr, int32_t *keep_count, int32_t *keep_rows,
-               hipStream_t s);
+                  float *scores_t, float *best_score, int Rs, hipStream_t s);
+int nms_adj_words(int R);            // 64-bit words per adjacency row (padded)
+size_t nms_workspace_bytes(int batch, int R, int C, size_t off[3]);
+int launch_nms(const float *boxes, const float *scores_t, const float *best_score, int batch,
+               int R, int Rs, int C, float score_thr, float iou_thr, void *workspace,
+               int32_t *keep_count, int32_t *keep_rows, hipStream_t s);
 int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
                     const int32_t *keep_rows, int batch, int R, int Rs, int C, int max_per_img,
                     float *dets, int32_t *labels, int32_t *rows, int32_t *num, hipStream_t s);
+size_t nms_single_workspace_bytes(int n);
 int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
-                      hipStream_t s);
+                      void *workspace, size_t workspace_bytes, hipStream_t s);
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 

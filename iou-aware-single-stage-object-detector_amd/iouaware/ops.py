@@ -147,7 +147,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     _lib.check(rc, 'ia_get_bboxes')
     if not debug:
         return dets, labels, rows, num
-    off = (C.c_size_t * 6)()
+    off = (C.c_size_t * 8)()
     _lib.check(L.ia_get_bboxes_workspace_layout(geom.ref(), B, C.byref(off)), 'workspace_layout')
 
     def view(i, dtype, shape):
@@ -189,14 +189,16 @@ def gather_decode(geom, cls, reg, iou, cand_idx, img_shapes, scale_factors, resc
     hw, sf = _meta_tensors(img_shapes, scale_factors, dev)
     boxes = torch.empty((B, geom.R, 4), dtype=torch.float32, device=dev)
     scores_t = torch.zeros((B, geom.C, geom.Rs), dtype=torch.float32, device=dev)
+    best = torch.empty((B, geom.R), dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().ia_gather_decode(geom.ref(), C.byref(p), B, dt, _ptr(cand_idx), _ptr(hw),
                                            _ptr(sf), int(bool(rescale)), _ptr(boxes),
-                                           _ptr(scores_t), _stream()), 'ia_gather_decode')
-    return boxes, scores_t
+                                           _ptr(scores_t), _ptr(best), _stream()),
+               'ia_gather_decode')
+    return boxes, scores_t, best
 
 
-def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img):
-    """boxes (B,R,4), scores_t (B,C,Rs) class-major."""
+def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img, best_score=None):
+    """boxes (B,R,4), scores_t (B,C,Rs) class-major; best_score (B,R) optional."""
     _require_gpu(boxes, 'boxes')
     B, Cn, Rs = scores_t.shape
     dev = boxes.device
@@ -206,11 +208,13 @@ def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img):
     num = torch.empty((B,), dtype=torch.int32, device=dev)
     kc = torch.empty((B, Cn), dtype=torch.int32, device=dev)
     kr = torch.empty((B, Cn, Rs), dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().ia_multiclass_nms_workspace_bytes(B, int(R), Cn)
+    ws = _workspace(dev, nbytes)
     _lib.check(_lib.lib().ia_multiclass_nms(_ptr(boxes.contiguous()), _ptr(scores_t.contiguous()),
-                                            B, int(R), Cn, float(score_thr), float(iou_thr),
-                                            int(max_per_img), _ptr(dets), _ptr(labels), _ptr(rows),
-                                            _ptr(num), _ptr(kc), _ptr(kr), _stream()),
-               'ia_multiclass_nms')
+                                            _ptr(best_score), B, int(R), Cn, float(score_thr),
+                                            float(iou_thr), int(max_per_img), _ptr(ws), nbytes,
+                                            _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num),
+                                            _ptr(kc), _ptr(kr), _stream()), 'ia_multiclass_nms')
     return dets, labels, rows, num, kc, kr
 
 
@@ -226,8 +230,10 @@ def nms_indices(dets, iou_thr):
     d = dets.detach().to(torch.float32).contiguous()
     keep = torch.empty((n,), dtype=torch.int32, device=dets.device)
     cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
-    _lib.check(_lib.lib().ia_nms(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _stream()),
-               'ia_nms')
+    nbytes = _lib.lib().ia_nms_workspace_bytes(n)
+    ws = _workspace(dets.device, nbytes)
+    _lib.check(_lib.lib().ia_nms(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _ptr(ws),
+                                 nbytes, _stream()), 'ia_nms')
     m = int(cnt.item())
     return keep[:m].to(torch.long)
 

@@ -186,8 +186,12 @@ def test_stage_entry_points(ops, oracle_lib):
     shapes, sfs = [(120, 157, 3)] * 2, [1.0, 1.3]
     rm = ops.decode_fuse_rowmax(geom, dc, dr, di)
     idx = ops.select_topk(geom, rm)
-    boxes, scores_t = ops.gather_decode(geom, dc, dr, di, idx, shapes, sfs, True)
-    d1 = ops.multiclass_nms(boxes, scores_t, geom.R, 0.05, 0.5, 100)
+    boxes, scores_t, best = ops.gather_decode(geom, dc, dr, di, idx, shapes, sfs, True)
+    assert torch.equal(best, scores_t[:, :, :geom.R].max(1).values)
+    d1 = ops.multiclass_nms(boxes, scores_t, geom.R, 0.05, 0.5, 100, best_score=best)
+    d0 = ops.multiclass_nms(boxes, scores_t, geom.R, 0.05, 0.5, 100)      # without the activity filter
+    for a, b in zip(d0[:5], d1[:5]):          # dets, labels, rows, num, keep_count
+        assert torch.equal(a, b)
     d2 = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, True, 0.05, 0.5, 100)
     torch.cuda.synchronize()
     for a, b in zip(d1[:4], d2):

@@ -30,8 +30,8 @@ def stage_times():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     ev[0].record(); rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
     ev[1].record(); idx = ops.select_topk(geom, rm)
-    ev[2].record(); boxes, st = ops.gather_decode(geom, cls, reg, iou, idx, shapes, sfs, True)
-    ev[3].record(); out = ops.multiclass_nms(boxes, st, geom.R, 0.05, 0.5, 100)
+    ev[2].record(); boxes, st, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, sfs, True)
+    ev[3].record(); out = ops.multiclass_nms(boxes, st, geom.R, 0.05, 0.5, 100, best_score=best)
     ev[4].record(); torch.cuda.synchronize()
     return [ev[i].elapsed_time(ev[i + 1]) for i in range(4)], out
 for _ in range(3): stage_times()
