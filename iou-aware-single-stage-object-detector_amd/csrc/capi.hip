@@ -37,6 +37,7 @@ static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
     w.off[6] = o; o = align_up(o + B * w.R * sizeof(float), 256);            // best_score
     size_t noff[3];
     w.off[7] = o; o = align_up(o + nms_workspace_bytes(batch, w.R, t.C, noff), 256);   // NMS stage
+    o = align_up(o + finalize_workspace_bytes(batch, w.Rs, t.C), 256);                 // + final keys
     w.total = o;
     return 0;
 }
@@ -115,7 +116,9 @@ size_t ia_multiclass_nms_workspace_bytes(int batch, int R, int C)
 {
     if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1) return 0;
     size_t off[3];
-    return ia::nms_workspace_bytes(batch, R, C, off);
+    const int Rs = (R + 63) / 64 * 64;
+    return (ia::nms_workspace_bytes(batch, R, C, off) + 255) / 256 * 256 +
+           ia::finalize_workspace_bytes(batch, Rs, C);
 }
 
 int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *best_score,
@@ -131,8 +134,11 @@ int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *be
     int rc = ia::launch_nms(boxes, scores_t, best_score, batch, R, Rs, C, score_thr, iou_thr,
                             workspace, keep_count, keep_rows, (hipStream_t)stream);
     if (rc) return rc;
+    size_t off[3];
+    char *fin_ws = static_cast<char *>(workspace) +
+                   (ia::nms_workspace_bytes(batch, R, C, off) + 255) / 256 * 256;
     return ia::launch_finalize(boxes, scores_t, keep_count, keep_rows, batch, R, Rs, C,
-                               max_per_img, dets, labels, rows, num, (hipStream_t)stream);
+                               max_per_img, fin_ws, dets, labels, rows, num, (hipStream_t)stream);
 }
 
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch)
@@ -184,8 +190,11 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
     if ((rc = ia::launch_nms(boxes, scores_t, best, batch, w.R, w.Rs, t.C, score_thr, iou_thr,
                              nms_ws, kc, kr, s)))
         return rc;
-    return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, dets,
-                               labels, rows, num, s);
+    size_t noff[3];
+    char *fin_ws = static_cast<char *>(nms_ws) +
+                   (ia::nms_workspace_bytes(batch, w.R, t.C, noff) + 255) / 256 * 256;
+    return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, fin_ws,
+                               dets, labels, rows, num, s);
 }
 
 size_t ia_nms_workspace_bytes(int n) { return ia::nms_single_workspace_bytes(n); }

@@ -465,11 +465,44 @@ int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, in
 // bbox_nms.py:49-56: concatenate kept boxes in class order; if more than
 // max_num remain, sort by score descending and keep the first max_num
 // (canonical tie order: position in the concatenation ascending).
+//   k_final_keys  one workgroup per (image, class): 64-bit keys
+//                 ordered(score)<<32 | ~position of its kept rows, written at the class's
+//                 offset in the image's flat concatenation (coalesced);
+//   k_finalize    one workgroup per image: radix top-k over the flat key array.
+struct FinalKeyArgs {
+    const float *scores_t;
+    const int32_t *keep_count;
+    const int32_t *keep_rows;
+    uint64_t *flat;          // (B, C*Rs)
+    int32_t Rs, C;
+};
+
+__global__ void __launch_bounds__(256) k_final_keys(FinalKeyArgs a)
+{
+    __shared__ uint32_t s_prefix;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int32_t *kc = a.keep_count + (size_t)b * a.C;
+    if (threadIdx.x < kWave) {
+        uint32_t part = 0;
+        for (int i = threadIdx.x; i < c; i += kWave) part += (uint32_t)kc[i];
+        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_down((int)part, off);
+        if (threadIdx.x == 0) s_prefix = part;
+    }
+    __syncthreads();
+    const uint32_t prefix = s_prefix, n = (uint32_t)kc[c];
+    const float *sc = a.scores_t + ((size_t)b * a.C + c) * a.Rs;
+    const int32_t *kr = a.keep_rows + ((size_t)b * a.C + c) * a.Rs;
+    uint64_t *out = a.flat + (size_t)b * a.C * a.Rs + prefix;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        out[i] = ((uint64_t)ordered_key(sc[kr[i]]) << 32) | (uint64_t)(0xffffffffu - (prefix + i));
+}
+
 struct FinalArgs {
     const float *boxes;
     const float *scores_t;
     const int32_t *keep_count;
     const int32_t *keep_rows;
+    const uint64_t *flat;
     float *dets;
     int32_t *labels;
     int32_t *rows;
@@ -496,10 +529,11 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
     }
     __syncthreads();
     const uint32_t total = prefix[C];
-    const uint32_t cap = (a.max_per_img < 0) ? total : (uint32_t)a.max_per_img;
+    const uint32_t cap = (uint32_t)a.max_per_img;
     const uint32_t nd = (total < cap) ? total : cap;
     const float *sct = a.scores_t + (size_t)b * C * a.Rs;
     const int32_t *kr = a.keep_rows + (size_t)b * C * a.Rs;
+    const uint64_t *flat = a.flat + (size_t)b * C * a.Rs;
     // position t in the concatenation -> (class, row)
     auto locate = [&](uint32_t t, int &c, int &r) {
         int lo = 0, hi = C;                     // largest c with prefix[c] <= t
@@ -511,15 +545,8 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
         r = kr[(size_t)c * a.Rs + (t - prefix[c])];
     };
     const bool need_sort = total > cap;
-    if (need_sort && nd > 0) {
-        auto key = [&](uint32_t t) -> uint64_t {
-            int c, r;
-            locate(t, c, r);
-            return ((uint64_t)ordered_key(sct[(size_t)c * a.Rs + r]) << 32) |
-                   (uint64_t)(0xffffffffu - t);
-        };
-        block_topk_desc(key, total, nd, sc, sel);
-    }
+    if (need_sort && nd > 0)
+        block_topk_desc([flat](uint32_t t) -> uint64_t { return flat[t]; }, total, nd, sc, sel);
     float *dets = a.dets + (size_t)b * a.max_per_img * 5;
     int32_t *labels = a.labels + (size_t)b * a.max_per_img;
     int32_t *rows = a.rows + (size_t)b * a.max_per_img;
@@ -541,16 +568,28 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
     if (tid == 0) a.num[b] = (int32_t)nd;
 }
 
+size_t finalize_workspace_bytes(int batch, int Rs, int C)
+{
+    return (size_t)batch * C * Rs * sizeof(uint64_t);
+}
+
 int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
                     const int32_t *keep_rows, int batch, int R, int Rs, int C, int max_per_img,
-                    float *dets, int32_t *labels, int32_t *rows, int32_t *num, hipStream_t s)
+                    void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
+                    hipStream_t s)
 {
     if (batch < 1 || C < 1 || C > kFinalMaxC || max_per_img < 1 || max_per_img > IA_MAX_PER_IMG)
         return IA_E_ARG;
-    if (!dets || !labels || !rows || !num) return IA_E_ARG;
+    if (!dets || !labels || !rows || !num || !workspace) return IA_E_ARG;
+    FinalKeyArgs k;
+    k.scores_t = scores_t; k.keep_count = keep_count; k.keep_rows = keep_rows;
+    k.flat = static_cast<uint64_t *>(workspace); k.Rs = Rs; k.C = C;
+    hipLaunchKernelGGL(k_final_keys, dim3((unsigned)C, (unsigned)batch), dim3(256), 0, s, k);
+    int rc = hip_status(hipGetLastError());
+    if (rc) return rc;
     FinalArgs a;
     a.boxes = boxes; a.scores_t = scores_t; a.keep_count = keep_count; a.keep_rows = keep_rows;
-    a.dets = dets; a.labels = labels; a.rows = rows; a.num = num;
+    a.flat = k.flat; a.dets = dets; a.labels = labels; a.rows = rows; a.num = num;
     a.R = R; a.Rs = Rs; a.C = C; a.max_per_img = max_per_img;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)batch), dim3(kFinalThreads), 0, s, a);
     return hip_status(hipGetLastError());
