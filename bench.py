@@ -61,7 +61,7 @@ TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nm
                 max_per_img=100)
 
 
-def build_model(device, fuse=True):
+def build_model(device, fuse=True, channels_last=False):
     torch.manual_seed(0)
     model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=None,
                                     test_cfg=ConfigDict(TEST_CFG))
@@ -69,6 +69,11 @@ def build_model(device, fuse=True):
     if fuse:
         from iouaware.fuse import fuse_inference
         fuse_inference(model)       # conv epilogues (BN / bias / add / ReLU) -> one HIP pass each
+    if channels_last:
+        # MIOpen's fp32 NHWC implicit-GEMM kernels beat the NCHW Winograd path on this net
+        # (tools/try_layouts.py); the three head outputs are brought back to NCHW by
+        # ops.level_ptrs (.contiguous()) for the HIP head kernels.
+        model = model.to(memory_format=torch.channels_last)
     return model
 
 
@@ -167,6 +172,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
+    ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -181,9 +187,11 @@ def main():
         dist.init_process_group(backend='nccl')
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
 
-    model = build_model(device, fuse=not args.no_fuse)
+    model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     imgs = torch.randn(BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
+    if not args.nchw:
+        imgs = imgs.contiguous(memory_format=torch.channels_last)
     stepper = Stepper(model, imgs, world)
 
     for _ in range(args.warmup):

@@ -189,6 +189,15 @@ int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const
 int ia_channel_affine_act(void *x, int dtype, const float *scale, const float *shift,
                           const void *residual, const float *res_scale, const float *res_shift,
                           int relu, int N, int C, int64_t HW, void *stream);
+/* the same on a channels-last tensor: x is (N, H, W, C) in memory (NHW = N*H*W);
+ * C must be a multiple of 4 (fp32) / 8 (bf16).                                 */
+int ia_channel_affine_act_nhwc(void *x, int dtype, const float *scale, const float *shift,
+                               const void *residual, const float *res_scale,
+                               const float *res_shift, int relu, int64_t NHW, int C, void *stream);
+
+/* (N, H*W, C) channels-last memory -> (N, C, H*W) NCHW memory (LDS-tiled transpose): lets the
+ * convolutions run in MIOpen's NHWC kernels while the head kernels read NCHW.    */
+int ia_nhwc_to_nchw(const void *src, void *dst, int dtype, int N, int C, int64_t HW, void *stream);
 
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the

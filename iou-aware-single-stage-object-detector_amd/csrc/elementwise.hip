@@ -107,7 +107,104 @@ __global__ void __launch_bounds__(kEwThreads) k_affine_act(AffineArgs a)
     }
 }
 
+// (N, HW, C) -> (N, C, HW) transpose through a padded 64x64 LDS tile: brings channels-last
+// head outputs (MIOpen's faster fp32 NHWC convolutions) to the NCHW layout of the head
+// kernels.  Reads are contiguous along C, writes contiguous along HW.
+template <typename T>
+__global__ void __launch_bounds__(256) k_nhwc_to_nchw(const T *src, T *dst, int C, int64_t HW)
+{
+    __shared__ T tile[64][65];
+    const int n = blockIdx.z;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const T *s = src + (size_t)n * HW * C;
+    T *d = dst + (size_t)n * HW * C;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll 4
+    for (int j = ty; j < 64; j += 4) {                           // j: position in tile
+        const int64_t p = p0 + j;
+        const int c = c0 + tx;
+        if (p < HW && c < C) tile[j][tx] = s[(size_t)p * C + c];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = ty; j < 64; j += 4) {                           // j: channel in tile
+        const int c = c0 + j;
+        const int64_t p = p0 + tx;
+        if (p < HW && c < C) d[(size_t)c * HW + p] = tile[tx][j];
+    }
+}
+
+// channels-last variant: x is (N, H, W, C) in memory, the channel is the fastest index
+template <typename T>
+__global__ void __launch_bounds__(kEwThreads) k_affine_act_nhwc(AffineArgs a, int64_t total)
+{
+    constexpr int N = Pack<T>::N;
+    using V = typename Pack<T>::V;
+    const bool has_res = a.res != nullptr;
+    T *x = static_cast<T *>(a.x);
+    const T *r = static_cast<const T *>(a.res);
+    for (int64_t i = ((int64_t)blockIdx.x * kEwThreads + threadIdx.x) * N; i < total;
+         i += (int64_t)gridDim.x * kEwThreads * N) {
+        const int c0 = (int)(i % a.C);
+        float v[N], w[N];
+        Pack<T>::unpack(*reinterpret_cast<const V *>(x + i), v);
+        if (has_res) Pack<T>::unpack(*reinterpret_cast<const V *>(r + i), w);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int c = c0 + j;
+            float y = v[j] * (a.scale ? a.scale[c] : 1.0f) + (a.shift ? a.shift[c] : 0.0f);
+            if (has_res)
+                y = y + (w[j] * (a.rscale ? a.rscale[c] : 1.0f) + (a.rshift ? a.rshift[c] : 0.0f));
+            v[j] = (a.relu && !(y > 0.0f)) ? ((y != y) ? y : 0.0f) : y;
+        }
+        *reinterpret_cast<V *>(x + i) = Pack<T>::pack(v);
+    }
+}
+
 }  // namespace ia
+
+extern "C" int ia_nhwc_to_nchw(const void *src, void *dst, int dtype, int N, int C, int64_t HW,
+                               void *stream)
+{
+    if (!src || !dst || N < 1 || C < 1 || HW < 1 || N > 65535) return IA_E_ARG;
+    dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)N);
+    if (grid.y > 65535) return IA_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == IA_F32)
+        hipLaunchKernelGGL(ia::k_nhwc_to_nchw<float>, grid, dim3(256), 0, s,
+                           static_cast<const float *>(src), static_cast<float *>(dst), C, HW);
+    else if (dtype == IA_BF16)
+        hipLaunchKernelGGL(ia::k_nhwc_to_nchw<uint16_t>, grid, dim3(256), 0, s,
+                           static_cast<const uint16_t *>(src), static_cast<uint16_t *>(dst), C, HW);
+    else return IA_E_ARG;
+    return ia::hip_status(hipGetLastError());
+}
+
+extern "C" int ia_channel_affine_act_nhwc(void *x, int dtype, const float *scale, const float *shift,
+                                          const void *residual, const float *res_scale,
+                                          const float *res_shift, int relu, int64_t NHW, int C,
+                                          void *stream)
+{
+    if (!x || NHW < 1 || C < 1) return IA_E_ARG;
+    const int n = dtype == IA_F32 ? 4 : (dtype == IA_BF16 ? 8 : 0);
+    if (n == 0 || C % n != 0 || ((uintptr_t)x & 15u) || (residual && ((uintptr_t)residual & 15u)))
+        return IA_E_ARG;
+    ia::AffineArgs a;
+    a.x = x; a.res = residual; a.scale = scale; a.shift = shift; a.rscale = res_scale;
+    a.rshift = res_shift; a.HW = 0; a.C = C; a.relu = relu;
+    const int64_t total = NHW * C;
+    int64_t blocks = (total / n + ia::kEwThreads - 1) / ia::kEwThreads;
+    blocks = (blocks + 3) / 4;                        // 4 packs per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == IA_F32)
+        hipLaunchKernelGGL(ia::k_affine_act_nhwc<float>, dim3((unsigned)blocks), dim3(ia::kEwThreads), 0, s, a, total);
+    else
+        hipLaunchKernelGGL(ia::k_affine_act_nhwc<uint16_t>, dim3((unsigned)blocks), dim3(ia::kEwThreads), 0, s, a, total);
+    return ia::hip_status(hipGetLastError());
+}
 
 extern "C" int ia_channel_affine_act(void *x, int dtype, const float *scale, const float *shift,
                                      const void *residual, const float *res_scale,

@@ -60,6 +60,8 @@ SIGNATURES = {
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_channel_affine_act': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    'ia_channel_affine_act_nhwc': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
+    'ia_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i64, _vp]),
     'ia_test_math': (_i, [_i, _vp, _vp, _vp, _i64, _vp]),
 }
 

@@ -73,6 +73,21 @@ class HeadGeometry(object):
         return C.byref(self.struct)
 
 
+def to_nchw(t):
+    """Contiguous NCHW view/copy of a 4-D tensor; channels-last inputs go through the
+    LDS-tiled HIP transpose instead of torch's generic strided copy."""
+    if t.is_contiguous():
+        return t
+    if t.dim() == 4 and t.is_cuda and t.is_contiguous(memory_format=torch.channels_last) \
+            and t.dtype in (torch.float32, torch.bfloat16):
+        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        n, c, h, w = t.shape
+        _lib.check(_lib.lib().ia_nhwc_to_nchw(_ptr(t), _ptr(out), _dtype_code(t), n, c, h * w,
+                                              _stream()), 'ia_nhwc_to_nchw')
+        return out
+    return t.contiguous()
+
+
 def level_ptrs(geom, cls, reg, iou):
     """Validate the per-level head outputs and pack their device pointers."""
     if not (len(cls) == len(reg) == len(iou) == geom.L):
@@ -90,9 +105,9 @@ def level_ptrs(geom, cls, reg, iou):
                                      % (name, l, tuple(t.shape), (B, ch, h, w)))
             if _dtype_code(t) != dt:
                 raise TypeError('mixed dtypes in head outputs')
-        cls[l] = cls[l].contiguous()
-        reg[l] = reg[l].contiguous()
-        iou[l] = iou[l].contiguous()
+        cls[l] = to_nchw(cls[l])
+        reg[l] = to_nchw(reg[l])
+        iou[l] = to_nchw(iou[l])
         p.cls[l], p.reg[l], p.iou[l] = cls[l].data_ptr(), reg[l].data_ptr(), iou[l].data_ptr()
     return p, B, dt
 
@@ -242,9 +257,19 @@ def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None
                         relu=False):
     """In place on a contiguous NCHW tensor: x = act(x*scale[c] + shift[c] [+ residual affine])."""
     _require_gpu(x, 'x')
-    if not x.is_contiguous():
-        raise ValueError('channel_affine_act_ needs a contiguous NCHW tensor')
     N, Cn = x.shape[0], x.shape[1]
+    if not x.is_contiguous():
+        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+            if residual is not None:
+                if residual.shape != x.shape or residual.dtype != x.dtype:
+                    raise ValueError('residual must match x')
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            _lib.check(_lib.lib().ia_channel_affine_act_nhwc(
+                _ptr(x), _dtype_code(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(res_scale),
+                _ptr(res_shift), int(bool(relu)), x.numel() // Cn, Cn, _stream()),
+                'ia_channel_affine_act_nhwc')
+            return x
+        raise ValueError('channel_affine_act_ needs a contiguous NCHW or channels-last tensor')
     hw = x.numel() // (N * Cn)
     if residual is not None:
         if residual.shape != x.shape or residual.dtype != x.dtype:

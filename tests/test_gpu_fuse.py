@@ -69,3 +69,23 @@ def test_fused_inference_matches_unfused(backbone):
     m.train()
     y = m.forward_head(x)
     assert y[0][0].requires_grad
+
+
+@pytest.mark.parametrize('shape', [(2, 720, 25, 42), (1, 9, 7, 11), (3, 36, 13, 21), (2, 64, 64, 64)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_nhwc_to_nchw_and_channels_last_epilogue(shape, dtype):
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(shape, device='cuda', generator=g).to(dtype)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    out = ops.to_nchw(xcl)
+    assert out.is_contiguous() and torch.equal(out, x)
+    if shape[1] % 8 == 0:
+        C = shape[1]
+        s, b = torch.randn(C, device='cuda', generator=g), torch.randn(C, device='cuda', generator=g)
+        r = torch.randn(shape, device='cuda', generator=g).to(dtype)
+        a = ops.channel_affine_act_(x.clone(), s, b, residual=r, relu=True)
+        c = ops.channel_affine_act_(xcl.clone(memory_format=torch.channels_last), s, b,
+                                    residual=r.contiguous(memory_format=torch.channels_last),
+                                    relu=True)
+        assert c.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, c)
