@@ -102,8 +102,11 @@ class Stepper(object):
         shapes = [x['img_shape'] for x in self.metas]
         factors = [x['scale_factor'] for x in self.metas]
         if timed:
-            # same five kernels as ops.get_bboxes, launched stage by stage so that HIP events
-            # on the launch stream bracket k_rowmax alone
+            # same kernels as ops.get_bboxes, launched stage by stage so that HIP events on the
+            # launch stream bracket k_rowmax alone (layout conversion first, outside the events)
+            cls = [ops.to_nchw(t) for t in cls]
+            reg = [ops.to_nchw(t) for t in reg]
+            iou = [ops.to_nchw(t) for t in iou]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
@@ -163,6 +166,21 @@ def cpu_baseline(model, stepper):
                        ' %d cores' % (t_conv, threads, t_post,
                                       int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum()),
                                       os.cpu_count()))
+
+
+def rowmax_traffic():
+    """HBM bytes per k_rowmax launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 correction 2 x FETCH_SIZE; tools/collect_pmc.sh).  It is a
+    batch-8 launch like the benchmark's; None when the profile is missing."""
+    path = os.path.join(ROOT, 'profiles', 'r01_head_pmc.json')
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        if prof.get('batch') != BATCH:
+            return None
+        return int(prof['kernels']['ia::k_rowmax<float>']['traffic_bytes_per_launch'])
+    except Exception:
+        return None
 
 
 def main():
@@ -233,7 +251,7 @@ def main():
                        'dets_per_image': int(stepper.last[2].float().mean().item())},
             'roofline': {'bound': 'hbm', 'kernel': 'k_rowmax', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': rowmax_traffic(),
                          'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
                          'avg_launch_ms': round(ms_rowmax, 4)},
         }
