@@ -37,6 +37,8 @@ extern "C" {
 #define IA_F32 0
 #define IA_BF16 1
 
+#define IA_LOSS_SLOTS 64     /* partial sums written by the *_fwd loss kernels */
+
 #define IA_E_ARG (-1)        /* invalid argument / unsupported size */
 #define IA_E_WORKSPACE (-2)  /* workspace too small */
 
@@ -128,9 +130,10 @@ int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *coun
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on
- * the NCHW head outputs directly.  Each *_fwd ADDS one fp64 sum (the
- * numerator the reference divides by avg_factor, losses.py:301-303,411,480)
- * into *loss_sum (device, zeroed by the caller; one fp64 atomic per workgroup);
+ * the NCHW head outputs directly.  Each *_fwd ADDS its fp64 partial sums into
+ * loss_sum[IA_LOSS_SLOTS] (device, zeroed by the caller; one fp64 atomic per
+ * workgroup, spread over the slots to avoid contention); the loss numerator the
+ * reference divides by avg_factor (losses.py:301-303,411,480) is the sum of the slots;
  * each *_bwd writes s * d(sum)/d(input) with the input's NCHW shape, where
  * s = gscale (host) * (gscale_dev ? *gscale_dev : 1): the upstream gradient
  * may stay on the device, so backward never synchronises with the host.       */

@@ -67,12 +67,15 @@ const char *ia_version(void) { return "iouaware-hip 0.1 (gfx950)"; }
 
 int ia_geom_sizes(const ia_head_geom *g, int32_t *N, int32_t *R, int32_t *Rs)
 {
-    ia::WsLayout w;
-    int rc = ia::ws_layout(g, 1, w);
+    // pure geometry: valid for any head, also when R exceeds what ia_get_bboxes supports
+    // (the training losses use a geometry with nms_pre <= 0, i.e. R = N)
+    ia::LevelTable t;
+    int rc = ia::make_level_table(g, t);
     if (rc) return rc;
-    if (N) *N = w.N;
-    if (R) *R = w.R;
-    if (Rs) *Rs = w.Rs;
+    const int32_t r = t.cand_off[t.num_levels];
+    if (N) *N = t.anchor_off[t.num_levels];
+    if (R) *R = r;
+    if (Rs) *Rs = (r + 63) / 64 * 64;
     return 0;
 }
 

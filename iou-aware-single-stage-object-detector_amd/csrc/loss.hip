@@ -38,7 +38,7 @@ __device__ __forceinline__ void block_sum_to(double v, double *dst, double *lds 
     if (tid == 0) {
         double s = 0.0;
         for (uint32_t w = 0; w < nw; ++w) s += lds[w];
-        atomicAdd(dst, s);
+        atomicAdd(dst + (blockIdx.x & (IA_LOSS_SLOTS - 1)), s);   // IA_LOSS_SLOTS partial sums
     }
 }
 
@@ -49,6 +49,18 @@ __device__ __forceinline__ float eff_scale(float host, const float *dev)
     return dev ? host * dev[0] : host;
 }
 
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp).  The loss kernels
+// stream 80 logits per anchor and must stay HBM-bound: the bit-reproducible software
+// exp/log/divide of ia_math.hpp (needed on the inference path for index parity) costs ~200
+// VALU slots per element here, 3x the budget of an 8 TB/s stream.  Losses have no index
+// outputs; their parity bar is the north star's 1e-4, checked against the oracle and the
+// reference's autograd.
+namespace fastm {
+__device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float log_(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+}  // namespace fastm
+
 // ------------------------------------------------------------------ focal
 struct FocalArgs {
     const void *cls;
@@ -57,66 +69,137 @@ struct FocalArgs {
     double *loss_sum;
     float *grad;
     int32_t B, A, C, HW;
+    int32_t cchunk;          // classes per wavefront (the class range is split over blockIdx.y)
     float gamma, alpha_pos, alpha_neg, gscale;
     const float *gscale_dev;
 };
 
-__device__ __forceinline__ void focal_elem(float x, bool t, float w0, const FocalArgs &a, float gs,
-                                           float &loss, float &grad, bool want_grad)
+// one element of py_sigmoid_focal_loss (losses.py:232-236) and its derivative w.r.t. the logit.
+// One exp, one reciprocal, one log: e = exp(-|x|); sigmoid and 1-sigmoid are e/(1+e), 1/(1+e).
+template <bool BWD, bool GAMMA2>
+__device__ __forceinline__ float focal_elem(float x, bool t, float at, float gamma, float gs)
 {
-    float pr = sigmoidf_(x);
-    float pt = t ? (1.0f - pr) : pr;
-    float at = (t ? a.alpha_pos : a.alpha_neg) * w0;
-    float mod = powf_pos_(pt, a.gamma);
-    float W = at * mod;
-    float bce = bce_logits_(x, t ? 1.0f : 0.0f);
-    loss = bce * W;
-    if (want_grad) {
-        float dbce = pr - (t ? 1.0f : 0.0f);
-        float dpt = pr * (1.0f - pr);
-        dpt = t ? -dpt : dpt;
-        float dmod;
-        if (a.gamma == 2.0f) dmod = 2.0f * pt;
-        else if (a.gamma == 1.0f) dmod = 1.0f;
-        else if (a.gamma == 0.0f) dmod = 0.0f;
-        else dmod = a.gamma * powf_pos_(pt, a.gamma - 1.0f);
-        float g = dbce * W + (bce * at) * (dmod * dpt);
-        grad = g * gs;
+    const float ax = __builtin_fabsf(x);
+    const float e = fastm::exp_(-ax);
+    const float inv = fastm::rcp_(1.0f + e);
+    const float hi = inv, lo = e * inv;                  // sigmoid(|x|), sigmoid(-|x|)
+    const bool pos = x >= 0.0f;
+    const float pr = pos ? hi : lo;                      // p
+    const float qr = pos ? lo : hi;                      // 1 - p  (no cancellation)
+    const float sp = fastm::log_(1.0f + e);              // log(1 + exp(-|x|))
+    const float bce = (t ? (pos ? 0.0f : ax) : (pos ? ax : 0.0f)) + sp;
+    const float pt = t ? qr : pr;
+    float mod, dmod;
+    if (GAMMA2) { mod = pt * pt; dmod = 2.0f * pt; }      // compile-time: no speculated log/exp
+    else {
+        const float lg = __builtin_amdgcn_logf(pt);      // log2
+        mod = __builtin_amdgcn_exp2f(gamma * lg);
+        dmod = gamma * __builtin_amdgcn_exp2f((gamma - 1.0f) * lg);
     }
+    if (!BWD) return bce * (at * mod);
+    const float dbce = t ? -qr : pr;                     // p - t
+    const float dpt = t ? -(pr * qr) : (pr * qr);
+    return (dbce * (at * mod) + (bce * at) * (dmod * dpt)) * gs;
 }
 
-constexpr int kLossTile = 256;
+template <typename T> struct LPack;
+template <> struct LPack<float> {
+    static constexpr int N = 4;
+    using V = float4;
+    static __device__ __forceinline__ void unpack(const V &q, float (&v)[4]) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+};
+template <> struct LPack<uint16_t> {
+    static constexpr int N = 4;
+    using V = ushort4;
+    static __device__ __forceinline__ void unpack(const V &q, float (&v)[4])
+    {
+        v[0] = bf16_to_f32(q.x); v[1] = bf16_to_f32(q.y); v[2] = bf16_to_f32(q.z); v[3] = bf16_to_f32(q.w);
+    }
+};
 
-template <typename T, bool BWD>
-__global__ void __launch_bounds__(1024) k_focal(FocalArgs a)
+// One wavefront per (image, anchor, tile of 256 positions) -- the row-max kernel's tiling:
+// every class-plane access is a contiguous 1 KiB segment, the label / weight of an anchor are
+// read once for all C classes.
+template <typename T, bool BWD, bool GAMMA2>
+__global__ void __launch_bounds__(64) k_focal(FocalArgs a)
 {
-    __shared__ double red[16];
-    const int lane = threadIdx.x, an = threadIdx.y;
+    const int lane = threadIdx.x;
     const int A = a.A, C = a.C, HW = a.HW;
-    const int tiles = (HW + kLossTile - 1) / kLossTile;
-    const int b = blockIdx.x / tiles;
-    const int p0 = (blockIdx.x - b * tiles) * kLossTile;
+    const int tiles = (HW + 255) / 256;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles; bid /= tiles;
+    const int an = bid % A;
+    const int b = bid / A;
+    const int p0 = tile * 256;
+    const int cbeg = blockIdx.y * a.cchunk;
+    const int cend = (cbeg + a.cchunk < C) ? (cbeg + a.cchunk) : C;
     const T *cls = static_cast<const T *>(a.cls) + ((size_t)b * A + an) * C * HW;
     float *grad = BWD ? a.grad + ((size_t)b * A + an) * C * HW : nullptr;
-    const size_t nbase = (size_t)b * HW * A;
-    double acc = 0.0;
     const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
+    const bool vec = (HW & 3) == 0;
+    int pos[4], pc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int p = p0 + lane + 64 * j;
-        if (p >= HW) continue;
-        const size_t n = nbase + (size_t)p * A + an;
-        const int64_t lab = a.labels[n];
-        const float w0 = a.label_weights[n];
-        for (int c = 0; c < C; ++c) {
-            float x = load_f32<T>(cls + (size_t)c * HW + p);
-            float l, g = 0.0f;
-            focal_elem(x, lab == (int64_t)(c + 1), w0, a, gs, l, g, BWD);
-            if (BWD) grad[(size_t)c * HW + p] = g;
-            else acc += (double)l;
+        pos[j] = vec ? (p0 + lane * 4 + j) : (p0 + lane + 64 * j);
+        pc[j] = (pos[j] < HW) ? pos[j] : (vec ? (HW - 4 + j) : (HW - 1));   // clamped: loads unconditional
+    }
+    int lab[4];
+    float at_pos[4], at_neg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t n = ((size_t)b * HW + pc[j]) * A + an;
+        lab[j] = (int)a.labels[n];
+        const float w0 = (pos[j] < HW) ? a.label_weights[n] : 0.0f;          // padding lanes weigh 0
+        at_pos[j] = a.alpha_pos * w0;
+        at_neg[j] = a.alpha_neg * w0;
+    }
+    float acc = 0.0f;
+    if (vec) {
+        const T *src = cls + pc[0];
+        constexpr int K = 8;                               // class planes in flight per wavefront
+        using V = typename LPack<T>::V;
+        for (int c0 = cbeg; c0 < cend; c0 += K) {
+            V q[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {                  // all loads first: independent, unconditional
+                const int c = (c0 + i < cend) ? (c0 + i) : (cend - 1);
+                q[i] = *reinterpret_cast<const V *>(src + (size_t)c * HW);
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int c = c0 + i;
+                if (c < cend) {                            // wave-uniform
+                    float v[4], o[4];
+                    LPack<T>::unpack(q[i], v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool t = lab[j] == c + 1;
+                        o[j] = focal_elem<BWD, GAMMA2>(v[j], t, t ? at_pos[j] : at_neg[j], a.gamma, gs);
+                        acc += o[j];
+                    }
+                    if (BWD && pos[0] < HW)
+                        *reinterpret_cast<float4 *>(grad + (size_t)c * HW + pc[0]) =
+                            make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (int c = cbeg; c < cend; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = load_f32<T>(cls + (size_t)c * HW + pc[j]);
+                const bool t = lab[j] == c + 1;
+                const float o = focal_elem<BWD, GAMMA2>(x, t, t ? at_pos[j] : at_neg[j], a.gamma, gs);
+                acc += o;
+                if (BWD && pos[j] < HW) grad[(size_t)c * HW + pos[j]] = o;
+            }
         }
     }
-    if (!BWD) block_sum_to(acc, a.loss_sum, red);
+    if (!BWD) {
+        double d = wave_sum((double)acc);
+        if (lane == 0) atomicAdd(a.loss_sum + ((blockIdx.x + blockIdx.y) & (IA_LOSS_SLOTS - 1)), d);
+    }
 }
 
 static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *labels,
@@ -132,14 +215,29 @@ static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *lab
     a.B = B; a.A = A; a.C = C; a.HW = HW; a.gamma = gamma; a.gscale = gscale; a.gscale_dev = gscale_dev;
     a.alpha_pos = alpha;
     a.alpha_neg = (float)(1.0 - (double)alpha);   // python: (1 - alpha) in double, then fp32
-    dim3 block(64, A), grid((unsigned)(B * ((HW + kLossTile - 1) / kLossTile)));
-    if (dtype == IA_F32) {
-        if (bwd) hipLaunchKernelGGL((k_focal<float, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_focal<float, false>), grid, block, 0, s, a);
-    } else if (dtype == IA_BF16) {
-        if (bwd) hipLaunchKernelGGL((k_focal<uint16_t, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_focal<uint16_t, false>), grid, block, 0, s, a);
-    } else return IA_E_ARG;
+    const int64_t blocks = (int64_t)B * A * ((HW + 255) / 256);
+    if (blocks > 2147483647LL) return IA_E_ARG;
+    // Small levels: split the class range over blockIdx.y so that there are >= ~2 wavefronts per
+    // SIMD (a lone wavefront runs the dependent exp/rcp/log chain at issue latency).  Large levels
+    // are NOT split: measured on MI355X (B=4, P3) 1/2/4/5/10 splits -> 49/50/63/64/89 us.
+    int split = (int)((2048 + blocks - 1) / blocks);
+    if (split < 1) split = 1;
+    if (split > (C + 7) / 8) split = (C + 7) / 8;
+    a.cchunk = ((C + split - 1) / split + 7) / 8 * 8;
+    const int ny = (C + a.cchunk - 1) / a.cchunk;
+    dim3 block(64), grid((unsigned)blocks, (unsigned)ny);
+    const bool g2 = gamma == 2.0f;
+#define IA_FOCAL(T)                                                                      \
+    do {                                                                                 \
+        if (bwd && g2) hipLaunchKernelGGL((k_focal<T, true, true>), grid, block, 0, s, a);    \
+        else if (bwd) hipLaunchKernelGGL((k_focal<T, true, false>), grid, block, 0, s, a);    \
+        else if (g2) hipLaunchKernelGGL((k_focal<T, false, true>), grid, block, 0, s, a);     \
+        else hipLaunchKernelGGL((k_focal<T, false, false>), grid, block, 0, s, a);            \
+    } while (0)
+    if (dtype == IA_F32) IA_FOCAL(float);
+    else if (dtype == IA_BF16) IA_FOCAL(uint16_t);
+    else return IA_E_ARG;
+#undef IA_FOCAL
     return hip_status(hipGetLastError());
 }
 
@@ -155,36 +253,43 @@ struct SmoothArgs {
     const float *gscale_dev;
 };
 
+// thread = (image, anchor, position); the 4 delta planes of an anchor are read coalesced along
+// the position, target / weight rows (16 B) from the (B, N_l, 4) arrays.  32-bit index math.
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
 {
     __shared__ double red[16];
     const int A = a.A, HW = a.HW;
-    const size_t total = (size_t)a.B * A * 4 * HW;
-    double acc = 0.0;
-    const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(e % HW);
-        const size_t q = e / HW;
-        const int k = (int)(q & 3);
-        const size_t ba = q >> 2;
-        const int an = (int)(ba % A);
-        const size_t b = ba / A;
-        const size_t n = ((b * HW + p) * A + an) * 4 + k;
-        float df = load_f32<T>(static_cast<const T *>(a.pred) + e) - a.target[n];
-        float d = __builtin_fabsf(df);
-        float w = a.weight[n];
-        if (BWD) {
-            float sgn = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
-            float g = (d < a.beta) ? df / a.beta : sgn;
-            a.grad[e] = (g * w) * gs;
-        } else {
-            float l = (d < a.beta) ? ((0.5f * d) * d) / a.beta : d - 0.5f * a.beta;
-            acc += (double)(l * w);
+    const int tiles = (HW + 255) / 256;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles; bid /= tiles;
+    const int an = bid % A;
+    const int b = bid / A;
+    const int p = tile * 256 + threadIdx.x;
+    float acc = 0.0f;
+    if (p < HW) {
+        const size_t n = ((size_t)b * HW + p) * A + an;
+        const float4 tg = reinterpret_cast<const float4 *>(a.target)[n];
+        const float4 wt = reinterpret_cast<const float4 *>(a.weight)[n];
+        const float tv[4] = {tg.x, tg.y, tg.z, tg.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
+        const size_t e0 = (((size_t)b * A + an) * 4) * HW + p;
+        const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t e = e0 + (size_t)k * HW;
+            float df = load_f32<T>(static_cast<const T *>(a.pred) + e) - tv[k];
+            float d = __builtin_fabsf(df);
+            if (BWD) {
+                float sgn = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
+                float g = (d < a.beta) ? df / a.beta : sgn;
+                a.grad[e] = (g * wv[k]) * gs;
+            } else {
+                float l = (d < a.beta) ? ((0.5f * d) * d) / a.beta : d - 0.5f * a.beta;
+                acc += l * wv[k];
+            }
         }
     }
-    if (!BWD) block_sum_to(acc, a.loss_sum, red);
+    if (!BWD) block_sum_to((double)acc, a.loss_sum, red);
 }
 
 static int launch_smooth(bool bwd, const void *pred, int dtype, const float *target,
@@ -196,9 +301,9 @@ static int launch_smooth(bool bwd, const void *pred, int dtype, const float *tar
     SmoothArgs a;
     a.pred = pred; a.target = target; a.weight = weight; a.loss_sum = loss_sum; a.grad = grad;
     a.B = B; a.A = A; a.HW = HW; a.beta = beta; a.gscale = gscale; a.gscale_dev = gscale_dev;
-    size_t total = (size_t)B * A * 4 * HW;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    const int64_t blocks = (int64_t)B * A * ((HW + 255) / 256);
+    if (blocks > 2147483647LL) return IA_E_ARG;
+    unsigned grid = (unsigned)blocks;
     if (dtype == IA_F32) {
         if (bwd) hipLaunchKernelGGL((k_smooth_l1<float, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_smooth_l1<float, false>), dim3(grid), dim3(256), 0, s, a);
@@ -261,15 +366,17 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
 {
     __shared__ double red[16];
     const int A = a.A, W = a.W, HW = a.H * a.W;
-    const size_t total = (size_t)a.B * A * HW;
     double acc = 0.0;
     const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(e % HW);
-        const size_t ba = e / HW;
-        const int an = (int)(ba % A);
-        const size_t b = ba / A;
+    const int tiles = (HW + 255) / 256;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles; bid /= tiles;
+    const int an = bid % A;
+    const size_t b = (size_t)(bid / A);
+    const int p = tile * 256 + threadIdx.x;
+    if (p < HW) {
+        const size_t ba = b * A + an;
+        const size_t e = ba * HW + p;
         const size_t n = (b * HW + p) * A + an;
         const int y = p / W, x = p - y * W;
         const float sx = (float)(x * a.stride), sy = (float)(y * a.stride);
@@ -347,9 +454,9 @@ static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void
     for (int k = 0; k < 4; ++k) { a.means[k] = g->means[k]; a.stds[k] = g->stds[k]; }
     a.B = B; a.A = g->num_anchors; a.H = g->H[level]; a.W = g->W[level];
     a.stride = g->stride[level]; a.gscale = gscale; a.gscale_dev = gscale_dev;
-    size_t total = (size_t)B * a.A * a.H * a.W;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
+    const int64_t blocks = (int64_t)B * a.A * ((a.H * a.W + 255) / 256);
+    if (blocks > 2147483647LL) return IA_E_ARG;
+    unsigned grid = (unsigned)blocks;
     if (dtype == IA_F32) {
         if (bwd) hipLaunchKernelGGL((k_iou_bce<float, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_iou_bce<float, false>), dim3(grid), dim3(256), 0, s, a);

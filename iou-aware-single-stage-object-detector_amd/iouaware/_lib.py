@@ -13,6 +13,7 @@ IA_MAX_NMS_PRE = 4096
 IA_MAX_CANDIDATES = 8192
 IA_MAX_PER_IMG = 1024
 IA_F32, IA_BF16 = 0, 1
+IA_LOSS_SLOTS = 64
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
 SO_PATH = os.path.abspath(os.path.join(_CSRC, 'libiouaware_hip.so'))

@@ -307,13 +307,13 @@ class _FocalLossFn(torch.autograd.Function):
         Cn = ch // A
         labels = labels.contiguous().view(-1).to(torch.int64)
         lw = label_weights.contiguous().view(-1).to(torch.float32)
-        acc = torch.zeros(1, dtype=torch.float64, device=cls.device)
+        acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=cls.device)
         _lib.check(_lib.lib().ia_focal_loss_fwd(_ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw),
                                                 B, A, Cn, H * W, float(gamma), float(alpha),
                                                 _ptr(acc), _stream()), 'ia_focal_loss_fwd')
         ctx.save_for_backward(cls, labels, lw)
         ctx.cfg = (A, Cn, float(gamma), float(alpha))
-        return acc.to(torch.float32)
+        return acc.sum().reshape(1).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -339,13 +339,13 @@ class _SmoothL1Fn(torch.autograd.Function):
         B, ch, H, W = pred.shape
         target = target.contiguous().to(torch.float32)
         weight = weight.contiguous().to(torch.float32)
-        acc = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=pred.device)
         _lib.check(_lib.lib().ia_smooth_l1_fwd(_ptr(pred), _dtype_code(pred), _ptr(target),
                                                _ptr(weight), B, A, H * W, float(beta), _ptr(acc),
                                                _stream()), 'ia_smooth_l1_fwd')
         ctx.save_for_backward(pred, target, weight)
         ctx.cfg = (A, float(beta))
-        return acc.to(torch.float32)
+        return acc.sum().reshape(1).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -373,14 +373,14 @@ class _IouBceFn(torch.autograd.Function):
         B = bbox_pred.shape[0]
         bt = bbox_targets.contiguous().to(torch.float32)
         bw = bbox_weights.contiguous().to(torch.float32)
-        acc = torch.zeros(1, dtype=torch.float64, device=bbox_pred.device)
+        acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=bbox_pred.device)
         _lib.check(_lib.lib().ia_iou_bce_fwd(geom.ref(), int(level), _ptr(bbox_pred), _ptr(iou_pred),
                                              _dtype_code(bbox_pred), _ptr(bt), _ptr(bw), B,
                                              C.c_void_p(0), _ptr(acc), _stream()),
                    'ia_iou_bce_fwd')
         ctx.save_for_backward(bbox_pred, iou_pred, bt, bw)
         ctx.cfg = (geom, int(level), bool(attach_target))
-        return acc.to(torch.float32)
+        return acc.sum().reshape(1).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -408,13 +408,13 @@ def iou_targets(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level):
     B = bbox_pred.shape[0]
     h, w = geom.featmap_sizes[level]
     out = torch.empty(B * h * w * geom.A, dtype=torch.float32, device=bbox_pred.device)
-    acc = torch.zeros(1, dtype=torch.float64, device=bbox_pred.device)
+    acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=bbox_pred.device)
     _lib.check(_lib.lib().ia_iou_bce_fwd(geom.ref(), int(level), _ptr(bbox_pred.contiguous()),
                                          _ptr(iou_pred.contiguous()), _dtype_code(bbox_pred),
                                          _ptr(bbox_targets.contiguous()),
                                          _ptr(bbox_weights.contiguous()), B, _ptr(out), _ptr(acc),
                                          _stream()), 'ia_iou_bce_fwd')
-    return out, acc
+    return out, acc.sum().reshape(1)
 
 
 class _SigmoidFocalLossOpFn(torch.autograd.Function):

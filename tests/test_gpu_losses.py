@@ -1,7 +1,9 @@
 """GPU (MI355X): the HIP loss kernels (csrc/loss.hip) through the C-ABI / the
-autograd wrappers, against the CPU oracle (elementwise gradients BIT-EXACT, sums
-within 1e-6 relative: the reduction order differs) and against the reference's
-own losses / autograd gradients in tests/golden/losses_small.npz (1e-4)."""
+autograd wrappers, against the CPU oracle (smooth-L1 / IoU-BCE elementwise
+gradients and IoU targets BIT-EXACT; focal within 1e-5 -- it uses the hardware
+transcendental units; sums within 2e-6 relative: the reduction order differs)
+and against the reference's own losses / autograd gradients in
+tests/golden/losses_small.npz (1e-4)."""
 import os
 
 import numpy as np
@@ -57,8 +59,12 @@ def test_focal_smoothl1_ioubce_vs_oracle_and_reference(ops, oracle_lib, fx):
         # --- vs oracle
         so, go = oracle_lib.focal_loss(cls[l], f['labels_%d' % l], f['label_weights_%d' % l],
                                        synth.A, 2.0, 0.25, gscale=float(gs))
-        assert rel(float(lc) / float(gs), so) < 1e-6
-        assert G.same_bits(c.grad.cpu().numpy(), go), 'focal grad level %d' % l
+        # focal runs on the hardware exp/log/rcp units (HBM-bound streaming kernel): not
+        # bit-identical to the oracle's software math, but far inside the 1e-4 bar
+        assert rel(float(lc) / float(gs), so) < 2e-6
+        gd = c.grad.cpu().numpy().astype(np.float64)
+        assert (np.abs(gd - go) <= 1e-5 * np.abs(go) + 1e-6 * np.abs(go).max()).all(), \
+            'focal grad level %d' % l
         so, go = oracle_lib.smooth_l1(reg[l], f['bbox_targets_%d' % l], f['bbox_weights_%d' % l],
                                       synth.A, 0.11, gscale=float(gs))
         assert abs(float(lb) / float(gs) - so) <= 1e-6 * max(abs(so), 1e-6)
