@@ -93,12 +93,25 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
         const int shift = 64 - bits_done - wb;
         for (uint32_t i = tid; i < nbins; i += nt) sc.hist[i] = 0;
         __syncthreads();
-        const uint32_t n_up = (n + kWave - 1) & ~(uint32_t)(kWave - 1);
-        for (uint32_t i = tid; i < n_up; i += nt) {
-            bool act = i < n;
-            uint64_t x = act ? key(i) : 0;
-            if (bits_done > 0) act = act && ((x >> (64 - bits_done)) == prefix);
-            hist_add(sc.hist, act, (uint32_t)(x >> shift) & (nbins - 1));
+        // U keys per thread are fetched before any of them is binned: the key functor is a
+        // global load, and one load per ballot round would leave the pass latency-bound
+        constexpr int U = 8;
+        for (uint32_t base = 0; base < n; base += nt * U) {
+            uint64_t xs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = base + u * nt + tid;
+                xs[u] = (i < n) ? key(i) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = base + u * nt + tid;
+                if (base + u * nt >= n) break;             // uniform
+                bool act = i < n;
+                const uint64_t x = xs[u];
+                if (bits_done > 0) act = act && ((x >> (64 - bits_done)) == prefix);
+                hist_add(sc.hist, act, (uint32_t)(x >> shift) & (nbins - 1));
+            }
         }
         __syncthreads();
         // find the digit d (from the top) where the running count reaches `need`
@@ -140,20 +153,30 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
     for (uint32_t i = tid; i < P; i += nt) sel[i] = 0;
     __syncthreads();
     const int rs = 64 - bits_done;
-    const uint32_t n_up = (n + kWave - 1) & ~(uint32_t)(kWave - 1);
-    for (uint32_t i = tid; i < n_up; i += nt) {
-        bool act = i < n;
-        uint64_t x = act ? key(i) : 0;
-        bool take = act && ((rs == 0 ? x : (x >> rs)) >= prefix);
-        uint64_t m = __ballot(take);
-        if (m) {
-            uint32_t base = 0;
-            int leader = __builtin_ctzll(m);
-            if (lane_id() == leader) base = atomicAdd(&sc.misc[3], (uint32_t)__builtin_popcountll(m));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (take) {
-                uint32_t pos = base + lane_prefix_popc(m);
-                if (pos < P) sel[pos] = x;
+    constexpr int U2 = 8;
+    for (uint32_t base = 0; base < n; base += nt * U2) {
+        uint64_t xs[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const uint32_t i = base + u * nt + tid;
+            xs[u] = (i < n) ? key(i) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const uint32_t i = base + u * nt + tid;
+            if (base + u * nt >= n) break;                 // uniform
+            const uint64_t x = xs[u];
+            bool take = (i < n) && ((rs == 0 ? x : (x >> rs)) >= prefix);
+            uint64_t m = __ballot(take);
+            if (m) {
+                uint32_t b0 = 0;
+                int leader = __builtin_ctzll(m);
+                if (lane_id() == leader) b0 = atomicAdd(&sc.misc[3], (uint32_t)__builtin_popcountll(m));
+                b0 = (uint32_t)__shfl((int)b0, leader);
+                if (take) {
+                    uint32_t pos = b0 + lane_prefix_popc(m);
+                    if (pos < P) sel[pos] = x;
+                }
             }
         }
     }

@@ -1,0 +1,46 @@
+"""GPU: BASELINE config 5 in miniature -- whole training iterations of IoU-aware RetinaNet
+R-50-FPN with the HIP loss kernels (forward_train -> losses -> backward -> clip -> SGD)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_iterations_run_and_learn():
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.train import build_optimizer, parse_losses, train_step
+    import bench
+    from test_host_targets import TRAIN_CFG
+    torch.manual_seed(0)
+    model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=TRAIN_CFG,
+                                    test_cfg=ConfigDict(bench.TEST_CFG)).cuda()
+    model.train()
+    opt = build_optimizer(model, dict(type='SGD', lr=0.005, momentum=0.9, weight_decay=0.0001))
+    B, ph, pw = 2, 256, 320
+    g = torch.Generator(device='cuda').manual_seed(3)
+    img = torch.randn(B, 3, ph, pw, device='cuda', generator=g)
+    gts, gls = synth.train_targets(11, B, ph, pw, max_gt=5)
+    gtb = [torch.from_numpy(x).cuda() for x in gts]
+    gtl = [torch.from_numpy(x).cuda() for x in gls]
+    metas = [synth.img_meta(ph, pw, ph, pw) for _ in range(B)]
+    frozen = model.backbone.layer1[0].conv1.weight.detach().clone()
+    head_w = model.bbox_head.retina_cls.weight.detach().clone()
+    hist = []
+    for _ in range(6):
+        lv = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+        assert set(lv) == {'loss_cls', 'loss_bbox', 'losses_iou', 'loss'}
+        assert all(np.isfinite(v) for v in lv.values())
+        assert abs(lv['loss'] - (lv['loss_cls'] + lv['loss_bbox'] + lv['losses_iou'])) < 1e-4 * lv['loss']
+        hist.append(lv['loss'])
+    assert hist[-1] < hist[0], hist                       # same batch 6 times: the loss goes down
+    assert torch.equal(model.backbone.layer1[0].conv1.weight, frozen)      # frozen_stages=1
+    assert not torch.equal(model.bbox_head.retina_cls.weight, head_w)
+    assert not model.backbone.bn1.training                                  # norm_eval
+    # every trainable parameter received a gradient (incl. retina_iou and the reg tower via the
+    # attached IoU target)
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
