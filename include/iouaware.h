@@ -82,8 +82,9 @@ int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int bat
 
 /* iou_aware_retina_head.py:536-544 (topk per level, descending; ties broken by
  * ascending anchor index).  cand_idx: (B, R) int32 level-local anchor index.  */
+size_t ia_select_topk_workspace_bytes(const ia_head_geom *g, int batch);
 int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_t *cand_idx,
-                   void *stream);
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* iou_aware_retina_head.py:545-558 + mmdet/core/bbox/transforms.py:44-78
  * (delta2bbox) + anchor_generator.py:53-70 (anchors regenerated, never read).

@@ -14,7 +14,7 @@ static void base_from_geom(const ia_head_geom *g, BaseAnchors &ba)
     memcpy(ba.v, g->base_anchors, sizeof(ba.v));
 }
 
-struct WsLayout { size_t off[8]; size_t total; int32_t N, R, Rs; };
+struct WsLayout { size_t off[9]; size_t total; int32_t N, R, Rs; };
 
 static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
 {
@@ -38,6 +38,7 @@ static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
     size_t noff[3];
     w.off[7] = o; o = align_up(o + nms_workspace_bytes(batch, w.R, t.C, noff), 256);   // NMS stage
     o = align_up(o + finalize_workspace_bytes(batch, w.Rs, t.C), 256);                 // + final keys
+    w.off[8] = o; o = align_up(o + select_workspace_bytes(t, batch), 256);             // top-k parts
     w.total = o;
     return 0;
 }
@@ -89,13 +90,22 @@ int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int bat
     return ia::launch_rowmax(t, *p, batch, dtype, rowmax, (hipStream_t)stream);
 }
 
+size_t ia_select_topk_workspace_bytes(const ia_head_geom *g, int batch)
+{
+    ia::LevelTable t;
+    if (ia::make_level_table(g, t) || batch < 1) return 0;
+    return ia::select_workspace_bytes(t, batch);
+}
+
 int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_t *cand_idx,
-                   void *stream)
+                   void *workspace, size_t workspace_bytes, void *stream)
 {
     ia::LevelTable t;
     int rc = ia::make_level_table(g, t);
     if (rc) return rc;
-    return ia::launch_select(t, rowmax, batch, cand_idx, (hipStream_t)stream);
+    if (batch < 1 || !workspace) return IA_E_ARG;
+    if (workspace_bytes < ia::select_workspace_bytes(t, batch)) return IA_E_WORKSPACE;
+    return ia::launch_select(t, rowmax, batch, cand_idx, workspace, (hipStream_t)stream);
 }
 
 int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
@@ -186,7 +196,7 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
     ia::BaseAnchors ba;
     ia::base_from_geom(g, ba);
     if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s))) return rc;
-    if ((rc = ia::launch_select(t, rowmax, batch, cand, s))) return rc;
+    if ((rc = ia::launch_select(t, rowmax, batch, cand, ws + w.off[8], s))) return rc;
     if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
                                 scale_factor, rescale, boxes, scores_t, best, w.Rs, s)))
         return rc;

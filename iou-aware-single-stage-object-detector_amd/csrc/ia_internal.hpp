@@ -44,8 +44,9 @@ inline int make_level_table(const ia_head_geom *g, LevelTable &t)
 // stage launchers (defined in the .hip files)
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
                   hipStream_t s);
+size_t select_workspace_bytes(const LevelTable &t, int batch);
 int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
-                  hipStream_t s);
+                  void *workspace, hipStream_t s);
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,

@@ -497,12 +497,16 @@ __global__ void __launch_bounds__(256) k_final_keys(FinalKeyArgs a)
         out[i] = ((uint64_t)ordered_key(sc[kr[i]]) << 32) | (uint64_t)(0xffffffffu - (prefix + i));
 }
 
+constexpr int kFinalParts = 16;      // workgroups per image for the first selection round
+
 struct FinalArgs {
     const float *boxes;
     const float *scores_t;
     const int32_t *keep_count;
     const int32_t *keep_rows;
     const uint64_t *flat;
+    uint64_t *part_keys;     // (B, kFinalParts, kpad): the parts' best max_per_img keys
+    int32_t kpad;
     float *dets;
     int32_t *labels;
     int32_t *rows;
@@ -512,6 +516,38 @@ struct FinalArgs {
 
 constexpr int kFinalThreads = 1024;
 constexpr int kFinalMaxC = 1024;
+
+// first round: each of kFinalParts workgroups keeps the best max_per_img keys of its slice of the
+// image's flat key array (one workgroup over up to 375k keys was issue-bound in one CU)
+__global__ void __launch_bounds__(kFinalThreads) k_finalize_part(FinalArgs a)
+{
+    __shared__ TopkScratch sc;
+    __shared__ uint64_t sel[IA_MAX_PER_IMG];
+    __shared__ uint32_t s_total;
+    const int part = blockIdx.x, b = blockIdx.y;
+    const uint32_t tid = threadIdx.x;
+    if (tid < kWave) {
+        uint32_t s = 0;
+        for (int c = tid; c < a.C; c += kWave) s += (uint32_t)a.keep_count[(size_t)b * a.C + c];
+        for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_down((int)s, off);
+        if (tid == 0) s_total = s;
+    }
+    __syncthreads();
+    const uint32_t total = s_total, cap = (uint32_t)a.max_per_img;
+    uint64_t *out = a.part_keys + ((size_t)b * kFinalParts + part) * a.kpad;
+    if (total <= cap) return;                              // no selection needed at all
+    const uint32_t chunk = (total + kFinalParts - 1) / kFinalParts;
+    const uint32_t beg = part * chunk;
+    const uint32_t cnt = (beg < total) ? ((total - beg < chunk) ? (total - beg) : chunk) : 0u;
+    const uint64_t *flat = a.flat + (size_t)b * a.C * a.Rs + beg;
+    const uint32_t kk = (cnt < cap) ? cnt : cap;
+    if (kk == cnt) {
+        for (uint32_t j = tid; j < (uint32_t)a.kpad; j += kFinalThreads) out[j] = (j < cnt) ? flat[j] : 0ull;
+        return;
+    }
+    block_topk_desc([flat](uint32_t t) -> uint64_t { return flat[t]; }, cnt, kk, sc, sel);
+    for (uint32_t j = tid; j < (uint32_t)a.kpad; j += kFinalThreads) out[j] = (j < kk) ? sel[j] : 0ull;
+}
 
 __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
 {
@@ -533,7 +569,6 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
     const uint32_t nd = (total < cap) ? total : cap;
     const float *sct = a.scores_t + (size_t)b * C * a.Rs;
     const int32_t *kr = a.keep_rows + (size_t)b * C * a.Rs;
-    const uint64_t *flat = a.flat + (size_t)b * C * a.Rs;
     // position t in the concatenation -> (class, row)
     auto locate = [&](uint32_t t, int &c, int &r) {
         int lo = 0, hi = C;                     // largest c with prefix[c] <= t
@@ -545,8 +580,12 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
         r = kr[(size_t)c * a.Rs + (t - prefix[c])];
     };
     const bool need_sort = total > cap;
-    if (need_sort && nd > 0)
-        block_topk_desc([flat](uint32_t t) -> uint64_t { return flat[t]; }, total, nd, sc, sel);
+    if (need_sort && nd > 0) {
+        // top-k of the union of the parts' survivors; unused slots are 0, below every real key
+        const uint64_t *pk = a.part_keys + (size_t)b * kFinalParts * a.kpad;
+        block_topk_desc([pk](uint32_t t) -> uint64_t { return pk[t]; },
+                        (uint32_t)(kFinalParts * a.kpad), nd, sc, sel);
+    }
     float *dets = a.dets + (size_t)b * a.max_per_img * 5;
     int32_t *labels = a.labels + (size_t)b * a.max_per_img;
     int32_t *rows = a.rows + (size_t)b * a.max_per_img;
@@ -568,9 +607,12 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
     if (tid == 0) a.num[b] = (int32_t)nd;
 }
 
+static int final_kpad() { return (IA_MAX_PER_IMG + 63) / 64 * 64; }
+
 size_t finalize_workspace_bytes(int batch, int Rs, int C)
 {
-    return (size_t)batch * C * Rs * sizeof(uint64_t);
+    return (size_t)batch * C * Rs * sizeof(uint64_t) +
+           (size_t)batch * kFinalParts * final_kpad() * sizeof(uint64_t);
 }
 
 int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
@@ -591,6 +633,10 @@ int launch_finalize(const float *boxes, const float *scores_t, const int32_t *ke
     a.boxes = boxes; a.scores_t = scores_t; a.keep_count = keep_count; a.keep_rows = keep_rows;
     a.flat = k.flat; a.dets = dets; a.labels = labels; a.rows = rows; a.num = num;
     a.R = R; a.Rs = Rs; a.C = C; a.max_per_img = max_per_img;
+    a.part_keys = k.flat + (size_t)batch * C * Rs;
+    a.kpad = (max_per_img + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_finalize_part, dim3(kFinalParts, (unsigned)batch), dim3(kFinalThreads), 0, s, a);
+    if ((rc = hip_status(hipGetLastError()))) return rc;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)batch), dim3(kFinalThreads), 0, s, a);
     return hip_status(hipGetLastError());
 }

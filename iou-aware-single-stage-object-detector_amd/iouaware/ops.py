@@ -192,8 +192,10 @@ def select_topk(geom, rowmax):
     rowmax = rowmax.contiguous()
     B = rowmax.shape[0]
     out = torch.empty((B, geom.R), dtype=torch.int32, device=rowmax.device)
-    _lib.check(_lib.lib().ia_select_topk(geom.ref(), _ptr(rowmax), B, _ptr(out), _stream()),
-               'ia_select_topk')
+    nbytes = _lib.lib().ia_select_topk_workspace_bytes(geom.ref(), B)
+    ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=rowmax.device)
+    _lib.check(_lib.lib().ia_select_topk(geom.ref(), _ptr(rowmax), B, _ptr(out), _ptr(ws), nbytes,
+                                         _stream()), 'ia_select_topk')
     return out
 
 
