@@ -173,6 +173,23 @@ int ia_iou_bce_bwd(const ia_head_geom *g, int level, const void *bbox_pred, cons
                    float gscale, const float *gscale_dev, float *grad_iou_pred,
                    float *grad_bbox_pred, void *stream);
 
+/* Training targets for a whole batch: anchor_target -> anchor_target_single ->
+ * MaxIoUAssigner.assign_wrt_overlaps + PseudoSampler + bbox2delta + unmap
+ * (mmdet/core/anchor/anchor_target.py:129-242, assigners/max_iou_assigner.py:98-201,
+ * bbox/geometry.py:48-64, bbox/transforms.py:6-41), gt_max_assign_all=True,
+ * allowed_border < 0, no ignore regions.  gt_boxes (B,gmax,4) fp32 padded,
+ * gt_labels (B,gmax) int64 or NULL (label 1), num_gt (B) >= 1, gmax <= 512;
+ * valid_hw (B,L,2) int32 = valid feature rows / cols per level (from pad_shape,
+ * anchor_head.py:135-146).  Outputs are level-major: for level l a (B, N_l[,4])
+ * block at element offset B * anchor_off_l -- the per-level tensors of
+ * images_to_levels.  counts (B,2): positives, negatives per image.
+ * gt_max_scratch: (B,gmax) uint32 scratch.                                      */
+int ia_anchor_targets(const ia_head_geom *g, const float *gt_boxes, const int64_t *gt_labels,
+                      const int32_t *num_gt, int batch, int gmax, const int32_t *valid_hw,
+                      float pos_iou_thr, float neg_iou_thr, float min_pos_iou, float pos_weight,
+                      uint32_t *gt_max_scratch, int64_t *labels, float *label_weights,
+                      float *bbox_targets, float *bbox_weights, int32_t *counts, void *stream);
+
 /* mmdet.ops.sigmoid_focal_loss: sigmoid_focal_loss_cuda.forward / .backward
  * (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-63,65-105;
  * binding sigmoid_focal_loss.cpp:17-43).  logits (N,C) fp32, targets (N) int64,

@@ -148,7 +148,7 @@ static int launch_adj(const float *boxes, int stride, const float *best_score, i
 // ------------------------------------------------------------------ per-problem order
 // k_class_sort: rows with score > score_thr of one (image, class), in canonical order
 // (score descending, row ascending) -> sorted_rows (uint16), n_in.
-constexpr int kSortThreads = 512;
+constexpr int kSortThreads = 1024;
 
 struct ClassSrc {                       // class-major fused scores of one problem
     const float *sc;

@@ -211,11 +211,23 @@ class IoUawareRetinaHead(AnchorHead):
                                                  num_total_samples)
         loss_iou = ops.iou_bce_sum(bbox_pred, iou_pred, bbox_targets.reshape(B, n_l, 4),
                                    bbox_weights.reshape(B, n_l, 4), geom, level,
-                                   self.attach_iou_target) * (1.0 / float(num_total_samples))
+                                   self.attach_iou_target) * (1.0 / num_total_samples)
         loss_cls = self.loss_cls.forward_level(cls_score, labels.reshape(B, n_l),
                                                label_weights.reshape(B, n_l), self.num_anchors,
                                                num_total_samples)
         return loss_cls, loss_bbox, loss_iou
+
+    def _device_targets_ok(self, cfg, gt_bboxes, gt_bboxes_ignore, device):
+        """the HIP assigner covers the IoU-aware configs' train_cfg (MaxIoUAssigner,
+        gt_max_assign_all, allowed_border=-1, no ignore regions, no sampling); anything else
+        takes the torch path in targets.py"""
+        a = cfg.assigner
+        return (device.type == 'cuda' and not self.sampling and isinstance(a, dict)
+                and a.get('type') == 'MaxIoUAssigner' and a.get('gt_max_assign_all', True)
+                and isinstance(a.get('neg_iou_thr'), float) and cfg.allowed_border < 0
+                and not (a.get('ignore_iof_thr', -1) > 0 and gt_bboxes_ignore is not None)
+                and all(g.shape[0] >= 1 for g in gt_bboxes)
+                and max(g.shape[0] for g in gt_bboxes) <= 512)
 
     def loss(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, gt_labels, img_metas, cfg,
              gt_bboxes_ignore=None):
@@ -226,17 +238,29 @@ class IoUawareRetinaHead(AnchorHead):
         if len(featmap_sizes) != len(self.anchor_generators):
             raise AssertionError('level count mismatch')
         device = cls_scores[0].device
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
-        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
-        targets = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas,
-                                self.target_means, self.target_stds, cfg,
-                                gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
-                                label_channels=label_channels, sampling=self.sampling)
-        if targets is None:
-            return None
-        labels, label_w, bbox_t, bbox_w, n_pos, n_neg, level_anchors = targets
-        num_total_samples = n_pos + n_neg if self.sampling else n_pos
         geom = self.geometry(featmap_sizes, -1)
+        if self._device_targets_ok(cfg, gt_bboxes, gt_bboxes_ignore, device):
+            # whole batch in two HIP launches, nothing returns to the host: the normaliser
+            # num_total_pos = sum_i max(n_pos_i, 1) (anchor_target.py:94) stays a device scalar
+            acfg = cfg.assigner
+            labels, label_w, bbox_t, bbox_w, counts = ops.anchor_targets(
+                geom, gt_bboxes, gt_labels, [m['pad_shape'] for m in img_metas],
+                acfg['pos_iou_thr'], acfg['neg_iou_thr'], acfg.get('min_pos_iou', .0),
+                cfg.pos_weight)
+            num_total_samples = counts[:, 0].clamp(min=1).sum().to(torch.float32)
+            level_anchors = [None] * len(featmap_sizes)
+        else:
+            anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
+            label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+            targets = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas,
+                                    self.target_means, self.target_stds, cfg,
+                                    gt_bboxes_ignore_list=gt_bboxes_ignore,
+                                    gt_labels_list=gt_labels, label_channels=label_channels,
+                                    sampling=self.sampling)
+            if targets is None:
+                return None
+            labels, label_w, bbox_t, bbox_w, n_pos, n_neg, level_anchors = targets
+            num_total_samples = n_pos + n_neg if self.sampling else n_pos
         out = [self.loss_single(cls_scores[l], bbox_preds[l], iou_preds[l], labels[l], label_w[l],
                                 bbox_t[l], bbox_w[l], level_anchors[l], num_total_samples,
                                 gt_bboxes, cfg, level=l, geom=geom)

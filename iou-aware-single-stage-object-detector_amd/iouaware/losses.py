@@ -30,7 +30,7 @@ class FocalLoss(nn.Module):
         """cls_score (B, A*C, H, W); labels (B, N_l) int64 in 0..C; label_weights (B, N_l)."""
         total = ops.focal_loss_sum(cls_score, labels, label_weights, num_anchors, self.gamma,
                                    self.alpha)
-        return total * (self.loss_weight / float(avg_factor))
+        return total * (self.loss_weight / avg_factor)      # avg_factor: python number or device scalar
 
     def forward(self, cls_score, label, label_weight, avg_factor=None, **kwargs):
         """cls_score (N, C); label (N, C) one-hot or (N,) integer 0..C; label_weight (N, C)
@@ -49,7 +49,7 @@ class FocalLoss(nn.Module):
         # an (N, C) row-major matrix is the NCHW layout with B=N, A=1, HW=1
         total = ops.focal_loss_sum(cls_score.reshape(n, c, 1, 1), label, label_weight, 1,
                                    self.gamma, self.alpha)
-        return total * (self.loss_weight / float(avg_factor))
+        return total * (self.loss_weight / avg_factor)      # avg_factor: python number or device scalar
 
 
 @LOSSES.register_module
@@ -61,7 +61,7 @@ class SmoothL1Loss(nn.Module):
     def forward_level(self, bbox_pred, bbox_targets, bbox_weights, num_anchors, avg_factor):
         """bbox_pred (B, A*4, H, W); targets / weights (B, N_l, 4)."""
         total = ops.smooth_l1_sum(bbox_pred, bbox_targets, bbox_weights, num_anchors, self.beta)
-        return total * (self.loss_weight / float(avg_factor))
+        return total * (self.loss_weight / avg_factor)      # avg_factor: python number or device scalar
 
     def forward(self, pred, target, weight, avg_factor=None, **kwargs):
         """pred / target / weight (N, 4)."""
@@ -72,4 +72,4 @@ class SmoothL1Loss(nn.Module):
         n = pred.shape[0]
         total = ops.smooth_l1_sum(pred.reshape(n, 4, 1, 1), target.reshape(n, 1, 4),
                                   weight.reshape(n, 1, 4), 1, self.beta)
-        return total * (self.loss_weight / float(avg_factor))
+        return total * (self.loss_weight / avg_factor)      # avg_factor: python number or device scalar

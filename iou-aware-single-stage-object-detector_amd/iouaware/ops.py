@@ -419,6 +419,54 @@ def iou_targets(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level):
     return out, acc.sum().reshape(1)
 
 
+def anchor_targets(geom, gt_bboxes, gt_labels, pad_shapes, pos_iou_thr, neg_iou_thr, min_pos_iou,
+                   pos_weight):
+    """Device target assignment for a batch.  gt_bboxes: list of (G_i,4) device tensors (G_i >= 1),
+    gt_labels: list of (G_i,) int64 tensors or None.  Returns per-level lists
+    labels[(B,N_l) i64], label_weights[(B,N_l)], bbox_targets[(B,N_l,4)], bbox_weights[(B,N_l,4)]
+    and counts (B,2) int32 (positives, negatives) -- all on the device, no host sync."""
+    B = len(gt_bboxes)
+    dev = gt_bboxes[0].device
+    _require_gpu(gt_bboxes[0], 'gt_bboxes')
+    sizes = [int(g_.shape[0]) for g_ in gt_bboxes]
+    if min(sizes) < 1:
+        raise ValueError('No gt or bboxes')
+    gmax = max(sizes)
+    boxes = torch.zeros((B, gmax, 4), dtype=torch.float32, device=dev)
+    labs = torch.zeros((B, gmax), dtype=torch.int64, device=dev) if gt_labels is not None else None
+    for i, g_ in enumerate(gt_bboxes):
+        boxes[i, :sizes[i]] = g_.to(torch.float32)
+        if labs is not None:
+            labs[i, :sizes[i]] = gt_labels[i].to(torch.int64)
+    num_gt = torch.tensor(sizes, dtype=torch.int32).to(dev, non_blocking=True)
+    vhw = []
+    for (h, w) in [tuple(p[:2]) for p in pad_shapes]:
+        vhw.append([[min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw)]
+                    for s, (fh, fw) in zip(geom.strides, geom.featmap_sizes)])
+    vhw = torch.tensor(vhw, dtype=torch.int32).to(dev, non_blocking=True)
+    N = geom.N
+    labels = torch.empty(B * N, dtype=torch.int64, device=dev)
+    lw = torch.empty(B * N, dtype=torch.float32, device=dev)
+    bt = torch.empty(B * N * 4, dtype=torch.float32, device=dev)
+    bw = torch.empty(B * N * 4, dtype=torch.float32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    scratch = torch.empty((B, gmax), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().ia_anchor_targets(
+        geom.ref(), _ptr(boxes), _ptr(labs), _ptr(num_gt), B, gmax, _ptr(vhw), float(pos_iou_thr),
+        float(neg_iou_thr), float(min_pos_iou), float(pos_weight), _ptr(scratch), _ptr(labels),
+        _ptr(lw), _ptr(bt), _ptr(bw), _ptr(counts), _stream()), 'ia_anchor_targets')
+    out = ([], [], [], [])
+    off = 0
+    for n_l in geom.level_anchors:
+        sl = slice(B * off, B * (off + n_l))
+        out[0].append(labels[sl].view(B, n_l))
+        out[1].append(lw[sl].view(B, n_l))
+        out[2].append(bt[4 * B * off:4 * B * (off + n_l)].view(B, n_l, 4))
+        out[3].append(bw[4 * B * off:4 * B * (off + n_l)].view(B, n_l, 4))
+        off += n_l
+    return out[0], out[1], out[2], out[3], counts
+
+
 class _SigmoidFocalLossOpFn(torch.autograd.Function):
     """the reference's mmdet.ops.sigmoid_focal_loss op (integer targets, no weights)."""
 
