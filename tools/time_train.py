@@ -1,0 +1,38 @@
+"""Scratch: BASELINE config 5 on one GPU -- training iterations of R-50 IoU-aware RetinaNet at
+800x1344, B images, HIP target assignment + loss kernels (no data-parallel all-reduce here)."""
+import sys, os, time
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
+import torch, bench, synth, iouaware
+from iouaware.config import ConfigDict
+from iouaware.train import build_optimizer, train_step
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+torch.backends.cudnn.benchmark = True
+TRAIN_CFG = ConfigDict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
+                                     ignore_iof_thr=-1), allowed_border=-1, pos_weight=-1, debug=False)
+torch.manual_seed(0)
+model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=TRAIN_CFG, test_cfg=ConfigDict(bench.TEST_CFG)).cuda().train()
+opt = build_optimizer(model, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001))
+img = torch.randn(B, 3, 800, 1344, device='cuda')
+if os.environ.get('CL'):
+    model = model.to(memory_format=torch.channels_last); img = img.contiguous(memory_format=torch.channels_last)
+gts, gls = synth.train_targets(5, B, 800, 1333, max_gt=20)
+gtb = [torch.from_numpy(x).cuda() for x in gts]; gtl = [torch.from_numpy(x).cuda() for x in gls]
+metas = [synth.img_meta(800, 1333, 800, 1344) for _ in range(B)]
+for _ in range(3): lv = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+torch.cuda.synchronize(); t = time.time(); n = 5
+for _ in range(n): lv = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+torch.cuda.synchronize(); dt = (time.time() - t) / n
+print('B=%d  %.1f ms/iter  %.1f img/s  loss %s  mem %.1f GB' % (B, dt * 1e3, B / dt, {k: round(v, 4) for k, v in lv.items()}, torch.cuda.max_memory_allocated() / 1e9))
+# loss part alone (targets + 3 losses fwd + bwd) on fixed head outputs
+with torch.no_grad():
+    outs = model.bbox_head(model.extract_feat(img))
+outs = [[t.detach().requires_grad_(True) for t in o] for o in outs]
+def loss_only():
+    losses = model.bbox_head.loss(*outs, gtb, gtl, metas, TRAIN_CFG)
+    sum(sum(v) for v in losses.values()).backward()
+for _ in range(3): loss_only()
+torch.cuda.synchronize(); t = time.time()
+for _ in range(10): loss_only()
+torch.cuda.synchronize(); print('targets + losses fwd+bwd: %.2f ms' % ((time.time() - t) / 10 * 1e3))
