@@ -109,6 +109,23 @@ int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *be
                       int32_t *rows, int32_t *num, int32_t *keep_count, int32_t *keep_rows,
                       void *stream);
 
+/* multiclass_nms with test_cfg.nms.type = 'soft_nms' (bbox_nms.py:29-56 ->
+ * mmdet/ops/nms/nms_wrapper.py:52-78 -> src/soft_nms_cpu.pyx:22-127): per class the
+ * boxes with score > score_thr go through soft-NMS in candidate order; survivors keep
+ * their DECAYED score; then the per-image top max_per_img.  method: IA_SOFT_LINEAR /
+ * IA_SOFT_GAUSSIAN (anything else: hard suppression, as in the .pyx).  Outputs as
+ * ia_multiclass_nms, except keep_rows lists each class's survivors in selection order
+ * and dets[...,4] are decayed scores.  workspace additionally holds the (B,C,Rs)
+ * decayed scores.                                                              */
+#define IA_SOFT_LINEAR 1
+#define IA_SOFT_GAUSSIAN 2
+size_t ia_multiclass_soft_nms_workspace_bytes(int batch, int R, int C);
+int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
+                           float score_thr, float iou_thr, int method, float sigma,
+                           float min_score, int max_per_img, void *workspace,
+                           size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
+                           int32_t *num, int32_t *keep_count, int32_t *keep_rows, void *stream);
+
 /* Whole path in one call (what the Python head calls).                        */
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
@@ -128,6 +145,13 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
 size_t ia_nms_workspace_bytes(int n);
 int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
            size_t workspace_bytes, void *stream);
+
+/* mmdet.ops.nms.soft_nms (nms_wrapper.py:52-78 -> soft_nms_cpu.pyx:22-127): dets (n,5)
+ * fp32 on device, n <= IA_MAX_CANDIDATES.  out_dets (n,5): surviving boxes in selection
+ * order with decayed scores; out_inds (n) int32 their input indices; count (1) int32.
+ * The reference runs this op on the host only (numpy); there is no reference CUDA path. */
+int ia_soft_nms(const float *dets, int n, float iou_thr, int method, float sigma, float min_score,
+                float *out_dets, int32_t *out_inds, int32_t *count, void *stream);
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on

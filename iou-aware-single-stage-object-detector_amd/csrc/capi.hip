@@ -54,6 +54,7 @@ __global__ void k_test_math(int op, const float *x, const float *y, float *out, 
         case 2: r = sigmoidf_(v); break;
         case 3: r = __builtin_sqrtf(v); break;
         case 4: r = v / y[i]; break;
+        case 6: r = (float)exp_f64_((double)(v / y[i])); break;
         default: r = sqrt_sigmoidf_(v); break;
         }
         out[i] = r;
@@ -154,6 +155,42 @@ int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *be
                                max_per_img, fin_ws, dets, labels, rows, num, (hipStream_t)stream);
 }
 
+size_t ia_multiclass_soft_nms_workspace_bytes(int batch, int R, int C)
+{
+    if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1) return 0;
+    const int Rs = (R + 63) / 64 * 64;
+    return ia::align_up((size_t)batch * C * Rs * sizeof(float), 256) +
+           ia::finalize_workspace_bytes(batch, Rs, C);
+}
+
+int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch, int R, int C,
+                           float score_thr, float iou_thr, int method, float sigma,
+                           float min_score, int max_per_img, void *workspace,
+                           size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
+                           int32_t *num, int32_t *keep_count, int32_t *keep_rows, void *stream)
+{
+    const int Rs = (R + 63) / 64 * 64;
+    if (!workspace) return IA_E_ARG;
+    if (workspace_bytes < ia_multiclass_soft_nms_workspace_bytes(batch, R, C) || workspace_bytes == 0)
+        return IA_E_WORKSPACE;
+    float *soft = static_cast<float *>(workspace);
+    int rc = ia::launch_soft_nms(boxes, scores_t, batch, R, Rs, C, score_thr, iou_thr, method,
+                                 sigma, min_score, keep_count, keep_rows, soft,
+                                 (hipStream_t)stream);
+    if (rc) return rc;
+    char *fin_ws = static_cast<char *>(workspace) +
+                   ia::align_up((size_t)batch * C * Rs * sizeof(float), 256);
+    return ia::launch_finalize(boxes, soft, keep_count, keep_rows, batch, R, Rs, C, max_per_img,
+                               fin_ws, dets, labels, rows, num, (hipStream_t)stream);
+}
+
+int ia_soft_nms(const float *dets, int n, float iou_thr, int method, float sigma, float min_score,
+                float *out_dets, int32_t *out_inds, int32_t *count, void *stream)
+{
+    return ia::launch_soft_nms_single(dets, n, iou_thr, method, sigma, min_score, out_dets,
+                                      out_inds, count, (hipStream_t)stream);
+}
+
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch)
 {
     ia::WsLayout w;
@@ -223,7 +260,7 @@ int ia_test_math(int op, const float *x, const float *y, float *out, int64_t n, 
 {
     if (n < 0 || op < 0 || op > 5) return IA_E_ARG;
     if (n == 0) return 0;
-    if (!x || !out || (op == 4 && !y)) return IA_E_ARG;
+    if (!x || !out || ((op == 4 || op == 6) && !y)) return IA_E_ARG;
     int64_t blocks = (n + 255) / 256;
     unsigned grid = (unsigned)(blocks > 8192 ? 8192 : blocks);
     hipLaunchKernelGGL(ia::k_test_math, dim3(grid), dim3(256), 0, (hipStream_t)stream, op, x, y,

@@ -67,4 +67,10 @@ int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, in
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
+int launch_soft_nms(const float *boxes, const float *scores_t, int batch, int R, int Rs, int C,
+                    float score_thr, float iou_thr, int method, float sigma, float min_score,
+                    int32_t *keep_count, int32_t *keep_rows, float *soft_scores, hipStream_t s);
+int launch_soft_nms_single(const float *dets, int n, float iou_thr, int method, float sigma,
+                           float min_score, float *out_dets, int32_t *out_inds, int32_t *count,
+                           hipStream_t s);
 }  // namespace ia

@@ -110,6 +110,33 @@ __device__ __forceinline__ float bce_logits_(float x, float t)
     return (mx - x * t) + softplus_negabs_(x);
 }
 
+// exp in fp64 (soft-NMS gaussian weights: the reference evaluates numpy's float64 exp and
+// casts to fp32, soft_nms_cpu.pyx:99).  Range reduction by ln2 in two parts, 13th-order
+// series in Horner form with fused multiply-adds, scaling by exponent bits in two steps:
+// the same operation sequence as the oracle's, hence the same bits.
+__device__ __forceinline__ double exp_f64_(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_huge_val();
+    if (x < -745.0) return 0.0;
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    const double inv_fact[12] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0,
+                                 1.0 / 362880.0,    1.0 / 40320.0,    1.0 / 5040.0,
+                                 1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,
+                                 1.0 / 6.0,         0.5,              1.0};
+    double p = 1.0 / 6227020800.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p = __builtin_fma(p, r, inv_fact[i]);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = (int)k;
+    const int k1 = ki / 2, k2 = ki - k1;
+    const double s1 = __builtin_bit_cast(double, (uint64_t)(k1 + 1023) << 52);
+    const double s2 = __builtin_bit_cast(double, (uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
 // order-preserving map float -> uint32 (larger float <-> larger key)
 __device__ __forceinline__ uint32_t ordered_key(float f)
 {

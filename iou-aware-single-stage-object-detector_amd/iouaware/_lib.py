@@ -47,6 +47,10 @@ SIGNATURES = {
     'ia_multiclass_nms_workspace_bytes': (_sz, [_i, _i, _i]),
     'ia_multiclass_nms': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp]),
+    'ia_multiclass_soft_nms_workspace_bytes': (_sz, [_i, _i, _i]),
+    'ia_multiclass_soft_nms': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _f, _f, _i, _vp, _sz, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp]),
+    'ia_soft_nms': (_i, [_vp, _i, _f, _i, _f, _f, _vp, _vp, _vp, _vp]),
     'ia_get_bboxes_workspace_bytes': (_sz, [_G, _i]),
     'ia_get_bboxes': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _sz, _vp, _vp, _vp,
                            _vp, _vp]),

@@ -171,9 +171,10 @@ class IoUawareRetinaHead(AnchorHead):
             raise NotImplementedError('softmax classification is outside the IoU-aware configs')
         nms_cfg = dict(cfg.nms)
         nms_type = nms_cfg.pop('type', 'nms')
-        if nms_type != 'nms':
-            raise NotImplementedError("test_cfg.nms.type='%s': only hard nms is built (soft_nms "
-                                      'is listed as next in SURVEY 8f)' % nms_type)
+        if nms_type not in ('nms', 'soft_nms'):
+            raise AttributeError("module 'nms_wrapper' has no attribute '%s'" % nms_type)
+        iou_thr = nms_cfg.pop('iou_thr')
+        soft = nms_cfg if nms_type == 'soft_nms' else None      # method / sigma / min_score
         featmap_sizes = [tuple(c.shape[-2:]) for c in cls_scores]
         geom = self.geometry(featmap_sizes, cfg.get('nms_pre', -1))
         shapes = [m['img_shape'] for m in img_metas]
@@ -182,7 +183,7 @@ class IoUawareRetinaHead(AnchorHead):
         bbox_preds = [b.detach() for b in bbox_preds]
         iou_preds = [i.detach() for i in iou_preds]
         return ops.get_bboxes(geom, cls_scores, bbox_preds, iou_preds, shapes, factors, rescale,
-                              cfg.score_thr, nms_cfg['iou_thr'], cfg.max_per_img)
+                              cfg.score_thr, iou_thr, cfg.max_per_img, soft=soft)
 
     def get_bboxes(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, gt_labels, img_metas, cfg,
                    rescale=False):

@@ -35,8 +35,27 @@ def nms(dets, iou_thr, device_id=None):
 
 
 def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
-    raise NotImplementedError('soft_nms is not on the IoU-aware configs\' path (test_cfg uses '
-                              "type='nms'); SURVEY 8f lists it as next")
+    """`mmdet.ops.nms.soft_nms` (nms_wrapper.py:52-78): -> (new_dets (m,5) with decayed scores
+    in selection order, inds (m,) int64), in the input's type.  The reference computes on the
+    host through numpy whatever the input is; this build computes on the device the tensor
+    lives on (a CPU tensor / ndarray is staged to the current ROCm device and back)."""
+    if isinstance(dets, torch.Tensor):
+        is_tensor, dets_th = True, dets
+    elif isinstance(dets, np.ndarray):
+        is_tensor, dets_th = False, torch.from_numpy(np.ascontiguousarray(dets, np.float32))
+    else:
+        raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
+            type(dets)))
+    ops._soft_method(method)                               # ValueError first (nms_wrapper.py:65-66)
+    src_device = dets_th.device
+    if not dets_th.is_cuda:
+        if not torch.cuda.is_available():
+            raise ops._lib.IouAwareLibraryError('soft_nms needs a ROCm device: no CPU path')
+        dets_th = dets_th.cuda()
+    new_dets, inds = ops.soft_nms_dets(dets_th, iou_thr, method, sigma, min_score)
+    if is_tensor:
+        return new_dets.to(device=src_device, dtype=dets.dtype), inds.to(src_device)
+    return new_dets.cpu().numpy().astype(np.float32), inds.cpu().numpy().astype(np.int64)
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
@@ -48,8 +67,9 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
     if score_factors is not None:
         raise NotImplementedError('score_factors is unused on this path')
     cfg = dict(nms_cfg)
-    if cfg.pop('type', 'nms') != 'nms':
-        raise NotImplementedError('only hard nms is built')
+    nms_type = cfg.pop('type', 'nms')
+    if nms_type not in ('nms', 'soft_nms'):
+        raise AttributeError("module 'nms_wrapper' has no attribute '%s'" % nms_type)
     n = multi_bboxes.shape[0]
     if n == 0:
         return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
@@ -59,7 +79,11 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
     Rs = (n + 63) // 64 * 64
     scores_t = multi_bboxes.new_zeros((1, Cn, Rs), dtype=torch.float32)
     scores_t[0, :, :n] = multi_scores[:, 1:].t().to(torch.float32)
-    out = ops.multiclass_nms(multi_bboxes.to(torch.float32).reshape(1, n, 4), scores_t, n,
-                             score_thr, cfg['iou_thr'], int(max_num))
+    boxes = multi_bboxes.to(torch.float32).reshape(1, n, 4)
+    if nms_type == 'soft_nms':
+        iou_thr = cfg.pop('iou_thr')
+        out = ops.multiclass_soft_nms(boxes, scores_t, n, score_thr, iou_thr, int(max_num), **cfg)
+    else:
+        out = ops.multiclass_nms(boxes, scores_t, n, score_thr, cfg['iou_thr'], int(max_num))
     k = int(out[3][0].item())
     return out[0][0, :k], out[1][0, :k].to(torch.long)

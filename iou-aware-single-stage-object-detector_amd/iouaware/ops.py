@@ -135,8 +135,11 @@ def _meta_tensors(img_shapes, scale_factors, device):
 
 
 def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr, iou_thr,
-               max_per_img, debug=False):
+               max_per_img, debug=False, soft=None):
     """Whole post-conv inference path for a batch.
+
+    soft: None for hard NMS (one C-ABI call), or dict(method=, sigma=, min_score=) for
+    test_cfg.nms.type='soft_nms' (the stage calls with ia_multiclass_soft_nms at the end).
 
     Returns device tensors dets (B,max_per_img,5) f32, labels (B,max_per_img) i32,
     rows (B,max_per_img) i32 (candidate row ids), num (B) i32.  With debug=True
@@ -144,6 +147,15 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     keep_count, keep_rows) for stage-level parity tests.
     """
     cls, reg, iou = list(cls), list(reg), list(iou)
+    if soft is not None:
+        cand = select_topk(geom, decode_fuse_rowmax(geom, cls, reg, iou))
+        boxes, scores_t, _ = gather_decode(geom, cls, reg, iou, cand, img_shapes, scale_factors,
+                                           rescale)
+        out = multiclass_soft_nms(boxes, scores_t, geom.R, score_thr, iou_thr, max_per_img, **soft)
+        if not debug:
+            return out[:4]
+        return out[:4] + (dict(cand_idx=cand, boxes=boxes, scores_t=scores_t, keep_count=out[4],
+                               keep_rows=out[5]),)
     p, B, dt = level_ptrs(geom, cls, reg, iou)
     dev = cls[0].device
     L = _lib.lib()
@@ -233,6 +245,59 @@ def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img, best_sco
                                             _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num),
                                             _ptr(kc), _ptr(kr), _stream()), 'ia_multiclass_nms')
     return dets, labels, rows, num, kc, kr
+
+
+SOFT_METHODS = {'linear': 1, 'gaussian': 2}
+
+
+def _soft_method(method):
+    if method not in SOFT_METHODS:
+        raise ValueError('Invalid method for SoftNMS: {}'.format(method))   # nms_wrapper.py:66
+    return SOFT_METHODS[method]
+
+
+def multiclass_soft_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img, method='linear',
+                        sigma=0.5, min_score=1e-3):
+    """like multiclass_nms with the soft-NMS operator per class: dets carry decayed scores and
+    keep_rows lists each class's survivors in selection order."""
+    _require_gpu(boxes, 'boxes')
+    B, Cn, Rs = scores_t.shape
+    dev = boxes.device
+    dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    rows = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    kc = torch.empty((B, Cn), dtype=torch.int32, device=dev)
+    kr = torch.empty((B, Cn, Rs), dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().ia_multiclass_soft_nms_workspace_bytes(B, int(R), Cn)
+    ws = _workspace(dev, nbytes)
+    _lib.check(_lib.lib().ia_multiclass_soft_nms(
+        _ptr(boxes.contiguous()), _ptr(scores_t.contiguous()), B, int(R), Cn, float(score_thr),
+        float(iou_thr), _soft_method(method), float(sigma), float(min_score), int(max_per_img),
+        _ptr(ws), nbytes, _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _ptr(kc), _ptr(kr),
+        _stream()), 'ia_multiclass_soft_nms')
+    return dets, labels, rows, num, kc, kr
+
+
+def soft_nms_dets(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """Device soft-NMS on (n,5) fp32 dets -> (new_dets (m,5), inds (m,) int64), selection order."""
+    _require_gpu(dets, 'dets')
+    n = dets.shape[0]
+    code = _soft_method(method)
+    if n == 0:
+        return dets.new_zeros((0, 5), dtype=torch.float32), dets.new_zeros(0, dtype=torch.long)
+    if n > _lib.IA_MAX_CANDIDATES:
+        raise _lib.IouAwareLibraryError('soft_nms supports at most %d boxes per call, got %d'
+                                        % (_lib.IA_MAX_CANDIDATES, n))
+    d = dets.detach().to(torch.float32).contiguous()
+    out = torch.empty((n, 5), dtype=torch.float32, device=dets.device)
+    inds = torch.empty((n,), dtype=torch.int32, device=dets.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    _lib.check(_lib.lib().ia_soft_nms(_ptr(d), n, float(iou_thr), code, float(sigma),
+                                      float(min_score), _ptr(out), _ptr(inds), _ptr(cnt),
+                                      _stream()), 'ia_soft_nms')
+    m = int(cnt.item())
+    return out[:m], inds[:m].to(torch.long)
 
 
 def nms_indices(dets, iou_thr):

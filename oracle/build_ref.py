@@ -50,6 +50,42 @@ def build(force=False):
     return OUT
 
 
+SOFT_SRC = '/root/reference/mmdet/ops/nms/src/soft_nms_cpu.pyx'
+SOFT_OUT = os.path.join(OUT_DIR, 'soft_nms_cpu.so')
+
+
+def build_soft(force=False):
+    """The reference's own soft-NMS (Cython) -> oracle/_ref/soft_nms_cpu.so.  The .pyx is
+    translated from where it lies; the generated C only exists in a temporary directory."""
+    if not os.path.exists(SOFT_SRC):
+        return None
+    if os.path.exists(SOFT_OUT) and not force and \
+            os.path.getmtime(SOFT_OUT) >= os.path.getmtime(SOFT_SRC):
+        return SOFT_OUT
+    import tempfile
+    import numpy
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        c_file = os.path.join(tmp, 'soft_nms_cpu.c')
+        subprocess.run([sys.executable, '-m', 'cython', '-3', SOFT_SRC, '-o', c_file], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run(['gcc', '-O2', '-fPIC', '-shared', '-w', c_file, '-o', SOFT_OUT,
+                        '-I' + numpy.get_include(), '-I' + sysconfig.get_paths()['include']],
+                       check=True)
+    return SOFT_OUT
+
+
+def load_soft():
+    """the reference module exposing soft_nms_cpu(boxes, iou_thr, method, sigma, min_score)"""
+    if not os.path.exists(SOFT_OUT):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('soft_nms_cpu', SOFT_OUT)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load():
     """Import the built module (None when it is not available)."""
     if not os.path.exists(OUT):
@@ -63,5 +99,6 @@ def load():
 
 
 if __name__ == '__main__':
-    out = build(force='--force' in sys.argv)
-    print('built' if out else 'reference not present; skipped', out or '')
+    for fn in (build, build_soft):
+        out = fn(force='--force' in sys.argv)
+        print('built' if out else 'reference not present; skipped', out or '')

@@ -114,4 +114,39 @@ static inline float ia_o_powf_pos(float x, float g)
     return ia_o_expf(g * ia_o_logf(x));
 }
 
+/* exp(x), fp64, ~1 ulp: k = rint(x/ln2), r = x - k ln2 (two-part), Taylor to r^13, 2^k by
+ * exponent bits.  Used where the reference calls numpy's float64 exp
+ * (soft_nms_cpu.pyx:104, gaussian weights); after the cast to fp32 it agrees with any
+ * faithfully rounded fp64 exp except on double-rounding coincidences (~1e-9 per value).
+ * Built from IEEE-exact fp64 operations only, restated independently in ia_math.hpp.   */
+static inline double ia_o_from_bits64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+static inline double ia_o_exp_f64(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return INFINITY;
+    if (x < -745.0) return 0.0;
+    double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;                  /* 1/13! */
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int ki = (int)k;
+    int k1 = ki / 2, k2 = ki - k1;
+    double s1 = ia_o_from_bits64((uint64_t)(k1 + 1023) << 52);
+    double s2 = ia_o_from_bits64((uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
 #endif

@@ -19,7 +19,8 @@ _i32p = C.POINTER(C.c_int32)
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in
-            ('iouaware_oracle.c', 'iouaware_oracle_loss.c', 'ia_oracle_math.h', 'Makefile')]
+            ('iouaware_oracle.c', 'iouaware_oracle_loss.c', 'iouaware_oracle_softnms.c',
+             'ia_oracle_math.h', 'Makefile')]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -220,3 +221,51 @@ def focal_loss_op(logits, targets, gamma, alpha, d_losses=None):
         lib().ia_o_focal_loss_op_bwd(_fp(logits), _i64p(targets), _fp(d), N, Cn, C.c_float(gamma),
                                      C.c_float(alpha), _fp(out))
     return out
+
+
+# ------------------------------------------------------------------ soft-NMS
+SOFT_METHODS = {'linear': 1, 'gaussian': 2}
+
+
+def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """soft_nms_cpu.pyx:22-127 -> (new_dets (m,5) fp32 with decayed scores, inds (m,) int64)."""
+    dets = _f(dets).reshape(-1, 5)
+    n = dets.shape[0]
+    out = np.zeros((max(n, 1), 5), np.float32)
+    inds = np.zeros(max(n, 1), np.int32)
+    m = lib().ia_o_soft_nms(_fp(dets), C.c_int(n), C.c_float(iou_thr),
+                            C.c_int(SOFT_METHODS.get(method, method) if isinstance(method, str)
+                                    else int(method)),
+                            C.c_float(sigma), C.c_float(min_score), _fp(out), _ip(inds))
+    return out[:m].copy(), inds[:m].astype(np.int64)
+
+
+def multiclass_soft_nms(bboxes, scores, score_thr, iou_thr, method='linear', sigma=0.5,
+                        min_score=1e-3, max_per_img=100):
+    """bbox_nms.py:29-56 with nms.type='soft_nms'; scores (R,C) without background column.
+    -> dict(det_bboxes (k,5), det_labels (k,), det_rows (k,), keep_count (C,), keep_rows (C,R),
+    keep_scores (C,R))"""
+    bboxes = _f(bboxes).reshape(-1, 4)
+    scores = _f(scores)
+    R, Cn = scores.shape
+    kc = np.zeros(Cn, np.int32)
+    kr = np.full((Cn, max(R, 1)), -1, np.int32)
+    ks = np.zeros((Cn, max(R, 1)), np.float32)
+    cap = max_per_img if max_per_img >= 0 else R * Cn
+    db = np.zeros((max(cap, 1), 5), np.float32)
+    dl = np.zeros(max(cap, 1), np.int32)
+    dr = np.zeros(max(cap, 1), np.int32)
+    nd = lib().ia_o_multiclass_soft_nms(
+        _fp(bboxes), _fp(scores), C.c_int(R), C.c_int(Cn), C.c_float(score_thr),
+        C.c_float(iou_thr), C.c_int(SOFT_METHODS[method]), C.c_float(sigma), C.c_float(min_score),
+        C.c_int(max_per_img), _ip(kc), _ip(kr), _fp(ks), _fp(db), _ip(dl), _ip(dr))
+    return dict(det_bboxes=db[:nd].copy(), det_labels=dl[:nd].astype(np.int64),
+                det_rows=dr[:nd].copy(), keep_count=kc, keep_rows=kr, keep_scores=ks)
+
+
+def vec_exp_f64(x):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    lib().ia_o_vec_exp_f64(x.ctypes.data_as(dp), y.ctypes.data_as(dp), C.c_longlong(x.size))
+    return y

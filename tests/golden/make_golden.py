@@ -266,6 +266,55 @@ def gen_get_bboxes():
         save('get_bboxes_full_%s' % kind, **out)
 
 
+# ---------------------------------------------------------------- soft-NMS
+def gen_soft_nms():
+    rs = np.random.RandomState(23)
+    out = {}
+    cases = [(1, 0.3, 'linear', 0.5, 1e-3), (2, 0.3, 'gaussian', 0.5, 1e-3),
+             (64, 0.3, 'linear', 0.5, 1e-3), (65, 0.5, 'gaussian', 0.5, 0.05),
+             (300, 0.3, 'linear', 0.5, 0.05), (300, 0.3, 'gaussian', 0.3, 0.1),
+             (1500, 0.5, 'linear', 0.5, 0.2), (1500, 0.5, 'gaussian', 1.0, 1e-3)]
+    for i, (n, thr, method, sigma, ms) in enumerate(cases):
+        dets = rand_dets(rs, n, span=200.0 if n < 1000 else 500.0)
+        nd, inds = nw.soft_nms(torch.from_numpy(dets), thr, method=method, sigma=sigma,
+                               min_score=ms)
+        out['dets_%d' % i] = dets
+        out['cfg_%d' % i] = np.array([thr, sigma, ms], np.float32)
+        out['method_%d' % i] = method
+        out['new_dets_%d' % i] = nd.numpy()
+        out['inds_%d' % i] = inds.numpy()
+        print('soft case', i, n, method, '->', nd.shape[0])
+    # tie-heavy case: quantised boxes and scores (positions decide, soft_nms_cpu.pyx:52-56)
+    d = rand_dets(rs, 200, span=80.0)
+    d[:, :4] = np.round(d[:, :4] / 16) * 16 + np.array([0, 0, 8, 8], np.float32)
+    d[:, 4] = np.round(d[:, 4] * 8) / 8 + 0.125
+    nd, inds = nw.soft_nms(torch.from_numpy(d), 0.3, method='linear', min_score=0.05)
+    out['ties_dets'], out['ties_new_dets'], out['ties_inds'] = d, nd.numpy(), inds.numpy()
+    out['num_cases'] = len(cases)
+    # whole get_bboxes with test_cfg.nms.type='soft_nms' on the 'small' synthetic head outputs
+    head = IoUawareRetinaHead(**HEAD_KW)
+    seed, B, ih, iw, ph, pw = 101, 2, 120, 157, 128, 160
+    cls, reg, iou = synth.head_outputs(seed, B, ph, pw, 'A')
+    metas = [synth.img_meta(ih, iw, ph, pw, 1.0), synth.img_meta(ih, iw, ph, pw, 1.6)]
+    t = lambda xs: [torch.from_numpy(x) for x in xs]   # noqa: E731
+    out['gb_seed'], out['gb_img'] = seed, np.array([ih, iw, ph, pw])
+    out['gb_checksum'] = synth.checksum(cls + reg + iou)
+    for v, nms in enumerate((dict(type='soft_nms', iou_thr=0.5, min_score=0.05),
+                             dict(type='soft_nms', iou_thr=0.3, method='gaussian', sigma=0.5,
+                                  min_score=0.05))):
+        cfg = ref_shim.to_cfg(dict(nms_pre=300, min_bbox_size=0, score_thr=0.05, nms=nms,
+                                   max_per_img=100))
+        for b in range(B):
+            sl = lambda xs: [x[b:b + 1] for x in t(xs)]    # noqa: E731
+            dets, labels = head.get_bboxes(sl(cls), sl(reg), sl(iou), [torch.zeros(0, 4)],
+                                           [torch.zeros(0, dtype=torch.long)], [metas[b]], cfg,
+                                           True)[0]
+            out['gb_dets_%d_%d' % (v, b)] = dets.numpy()
+            out['gb_labels_%d_%d' % (v, b)] = labels.numpy()
+            print('soft get_bboxes', v, b, dets.shape, float(dets[:, 4].min()))
+    save('soft_nms', **out)
+
+
 # ---------------------------------------------------------------- losses (T1..T3)
 def gen_losses():
     head = IoUawareRetinaHead(**HEAD_KW)
@@ -365,6 +414,6 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'losses', 'model']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'model']
     for w in which:
         globals()['gen_' + w]()

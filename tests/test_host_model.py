@@ -126,12 +126,17 @@ def test_get_bboxes_refuses_cpu_tensors():
         m.bbox_head.get_bboxes(*outs, None, None, meta, m.test_cfg, True)
 
 
-def test_soft_nms_and_unknown_nms_type_rejected():
+def test_nms_ops_reject_like_the_reference():
     from iouaware import nms_op
-    with pytest.raises(NotImplementedError):
-        nms_op.soft_nms(torch.zeros(1, 5), 0.5)
+    with pytest.raises(ValueError):                       # nms_wrapper.py:66
+        nms_op.soft_nms(torch.zeros(1, 5), 0.5, method='quadratic')
+    with pytest.raises(TypeError):                        # nms_wrapper.py:59-62
+        nms_op.soft_nms([1, 2, 3], 0.5)
     with pytest.raises(TypeError):
         nms_op.nms([1, 2, 3], 0.5)
+    with pytest.raises(AttributeError):                   # getattr(nms_wrapper, type), bbox_nms.py:31
+        nms_op.multiclass_nms(torch.zeros(1, 4), torch.zeros(1, 3), 0.05,
+                              dict(type='hard_nms', iou_thr=0.5))
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG_DIR), reason='reference tree absent (GPU box)')
