@@ -258,7 +258,7 @@ int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *coun
 
 int ia_test_math(int op, const float *x, const float *y, float *out, int64_t n, void *stream)
 {
-    if (n < 0 || op < 0 || op > 5) return IA_E_ARG;
+    if (n < 0 || op < 0 || op > 6) return IA_E_ARG;
     if (n == 0) return 0;
     if (!x || !out || ((op == 4 || op == 6) && !y)) return IA_E_ARG;
     int64_t blocks = (n + 255) / 256;
