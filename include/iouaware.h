@@ -183,6 +183,32 @@ int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const flo
                      int B, int A, int HW, float beta, float gscale, const float *gscale_dev,
                      float *grad_pred, void *stream);
 
+/* The IoU-balanced variants (loss_cls.type='IOUbalancedSigmoidFocalLoss', losses.py:309-374;
+ * loss_bbox.type='IoUbalancedSmoothL1Loss', losses.py:416-458; anchor_head.py:83-84).
+ * anchor_iou (B*N_l): the IoU regression target of the level (ia_iou_bce_fwd's iou_target),
+ * treated as a constant.
+ * focal: the positive element of a positive anchor is weighted by iou^eta * normalizer,
+ * normalizer = S1 / (S2 + 1e-6).  fwd ADDS into loss_sums3[3*IA_LOSS_SLOTS]: slots [0,64) the
+ * t=0 elements, [64,128) S1 = sum_pos loss, [128,192) S2 = sum_pos loss * iou^eta; the loss is
+ * S0 + normalizer*S2.  bwd reads the normalizer from a device scalar.
+ * smooth-L1: weight * iou^delta.                                                          */
+int ia_focal_loss_balanced_fwd(const void *cls, int dtype, const int64_t *labels,
+                               const float *label_weights, const float *anchor_iou, int B, int A,
+                               int C, int HW, float gamma, float alpha, float eta,
+                               double *loss_sums3, void *stream);
+int ia_focal_loss_balanced_bwd(const void *cls, int dtype, const int64_t *labels,
+                               const float *label_weights, const float *anchor_iou, int B, int A,
+                               int C, int HW, float gamma, float alpha, float eta,
+                               const float *normalizer_dev, float gscale, const float *gscale_dev,
+                               float *grad_cls, void *stream);
+int ia_smooth_l1_balanced_fwd(const void *pred, int dtype, const float *target,
+                              const float *weight, const float *anchor_iou, int B, int A, int HW,
+                              float beta, float delta, double *loss_sum, void *stream);
+int ia_smooth_l1_balanced_bwd(const void *pred, int dtype, const float *target,
+                              const float *weight, const float *anchor_iou, int B, int A, int HW,
+                              float beta, float delta, float gscale, const float *gscale_dev,
+                              float *grad_pred, void *stream);
+
 /* IoU target (delta2bbox x2 + aligned bbox_overlaps,
  * iou_aware_retina_head.py:256-259, mmdet/core/bbox/geometry.py:34-47) fused
  * with weighted_iou_regression_loss (losses.py:460-480).  `level` selects the

@@ -72,6 +72,11 @@ struct FocalArgs {
     int32_t cchunk;          // classes per wavefront (the class range is split over blockIdx.y)
     float gamma, alpha_pos, alpha_neg, gscale;
     const float *gscale_dev;
+    // IoU-balanced variant (losses.py:309-374): per-anchor IoU, exponent, and (backward) the
+    // normalizer S1 / (S2 + 1e-6) as a device scalar
+    const float *anchor_iou;
+    const float *pos_scale_dev;
+    float eta;
 };
 
 // one element of py_sigmoid_focal_loss (losses.py:232-236) and its derivative w.r.t. the logit.
@@ -120,7 +125,10 @@ template <> struct LPack<uint16_t> {
 // One wavefront per (image, anchor, tile of 256 positions) -- the row-max kernel's tiling:
 // every class-plane access is a contiguous 1 KiB segment, the label / weight of an anchor are
 // read once for all C classes.
-template <typename T, bool BWD, bool GAMMA2>
+// BAL: the positive element of a positive anchor is weighted by iou^eta * normalizer; the forward
+// accumulates S0 (t = 0 elements), S1 = sum_pos loss, S2 = sum_pos loss * iou^eta in
+// loss_sum[0:64], [64:128], [128:192].
+template <typename T, bool BWD, bool GAMMA2, bool BAL>
 __global__ void __launch_bounds__(64) k_focal(FocalArgs a)
 {
     const int lane = threadIdx.x;
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(64) k_focal(FocalArgs a)
         pc[j] = (pos[j] < HW) ? pos[j] : (vec ? (HW - 4 + j) : (HW - 1));   // clamped: loads unconditional
     }
     int lab[4];
-    float at_pos[4], at_neg[4];
+    float at_pos[4], at_neg[4], iw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const size_t n = ((size_t)b * HW + pc[j]) * A + an;
@@ -152,8 +160,20 @@ __global__ void __launch_bounds__(64) k_focal(FocalArgs a)
         const float w0 = (pos[j] < HW) ? a.label_weights[n] : 0.0f;          // padding lanes weigh 0
         at_pos[j] = a.alpha_pos * w0;
         at_neg[j] = a.alpha_neg * w0;
+        iw[j] = 1.0f;
+        if (BAL) {                                         // (t * iou)^eta, times the normalizer
+            iw[j] = __builtin_amdgcn_exp2f(a.eta * __builtin_amdgcn_logf(a.anchor_iou[n]));
+            if (BWD) iw[j] *= a.pos_scale_dev[0];
+        }
     }
-    float acc = 0.0f;
+    float acc = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+    auto account = [&](float &o, bool t, int j) {
+        if (!BAL) { acc += o; return; }
+        if (BWD) { o = t ? o * iw[j] : o; return; }
+        acc += t ? 0.0f : o;
+        acc1 += t ? o : 0.0f;
+        acc2 += t ? o * iw[j] : 0.0f;
+    };
     if (vec) {
         const T *src = cls + pc[0];
         constexpr int K = 8;                               // class planes in flight per wavefront
@@ -175,7 +195,7 @@ __global__ void __launch_bounds__(64) k_focal(FocalArgs a)
                     for (int j = 0; j < 4; ++j) {
                         const bool t = lab[j] == c + 1;
                         o[j] = focal_elem<BWD, GAMMA2>(v[j], t, t ? at_pos[j] : at_neg[j], a.gamma, gs);
-                        acc += o[j];
+                        account(o[j], t, j);
                     }
                     if (BWD && pos[0] < HW)
                         *reinterpret_cast<float4 *>(grad + (size_t)c * HW + pc[0]) =
@@ -190,23 +210,34 @@ __global__ void __launch_bounds__(64) k_focal(FocalArgs a)
             for (int j = 0; j < 4; ++j) {
                 const float x = load_f32<T>(cls + (size_t)c * HW + pc[j]);
                 const bool t = lab[j] == c + 1;
-                const float o = focal_elem<BWD, GAMMA2>(x, t, t ? at_pos[j] : at_neg[j], a.gamma, gs);
-                acc += o;
+                float o = focal_elem<BWD, GAMMA2>(x, t, t ? at_pos[j] : at_neg[j], a.gamma, gs);
+                account(o, t, j);
                 if (BWD && pos[j] < HW) grad[(size_t)c * HW + pos[j]] = o;
             }
         }
     }
     if (!BWD) {
         double d = wave_sum((double)acc);
-        if (lane == 0) atomicAdd(a.loss_sum + ((blockIdx.x + blockIdx.y) & (IA_LOSS_SLOTS - 1)), d);
+        const int slot = (blockIdx.x + blockIdx.y) & (IA_LOSS_SLOTS - 1);
+        if (lane == 0) atomicAdd(a.loss_sum + slot, d);
+        if (BAL && __ballot(acc1 != 0.0f || acc2 != 0.0f)) {         // positives are rare
+            const double d1 = wave_sum((double)acc1), d2 = wave_sum((double)acc2);
+            if (lane == 0) {
+                atomicAdd(a.loss_sum + IA_LOSS_SLOTS + slot, d1);
+                atomicAdd(a.loss_sum + 2 * IA_LOSS_SLOTS + slot, d2);
+            }
+        }
     }
 }
 
 static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *labels,
                         const float *lw, int B, int A, int C, int HW, float gamma, float alpha,
                         float gscale, const float *gscale_dev, double *loss_sum, float *grad,
-                        hipStream_t s)
+                        hipStream_t s, const float *anchor_iou = nullptr, float eta = 0.0f,
+                        const float *pos_scale_dev = nullptr)
 {
+    const bool bal = anchor_iou != nullptr;
+    if (bal && (!(eta > 0.0f) || (bwd && !pos_scale_dev))) return IA_E_ARG;
     if (!cls || !labels || !lw || B < 1 || A < 1 || A > IA_MAX_ANCHORS || C < 1 || HW < 1)
         return IA_E_ARG;
     if (bwd ? !grad : !loss_sum) return IA_E_ARG;
@@ -215,6 +246,7 @@ static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *lab
     a.B = B; a.A = A; a.C = C; a.HW = HW; a.gamma = gamma; a.gscale = gscale; a.gscale_dev = gscale_dev;
     a.alpha_pos = alpha;
     a.alpha_neg = (float)(1.0 - (double)alpha);   // python: (1 - alpha) in double, then fp32
+    a.anchor_iou = anchor_iou; a.eta = eta; a.pos_scale_dev = pos_scale_dev;
     const int64_t blocks = (int64_t)B * A * ((HW + 255) / 256);
     if (blocks > 2147483647LL) return IA_E_ARG;
     // Small levels: split the class range over blockIdx.y so that there are >= ~2 wavefronts per
@@ -227,15 +259,15 @@ static int launch_focal(bool bwd, const void *cls, int dtype, const int64_t *lab
     const int ny = (C + a.cchunk - 1) / a.cchunk;
     dim3 block(64), grid((unsigned)blocks, (unsigned)ny);
     const bool g2 = gamma == 2.0f;
-#define IA_FOCAL(T)                                                                      \
-    do {                                                                                 \
-        if (bwd && g2) hipLaunchKernelGGL((k_focal<T, true, true>), grid, block, 0, s, a);    \
-        else if (bwd) hipLaunchKernelGGL((k_focal<T, true, false>), grid, block, 0, s, a);    \
-        else if (g2) hipLaunchKernelGGL((k_focal<T, false, true>), grid, block, 0, s, a);     \
-        else hipLaunchKernelGGL((k_focal<T, false, false>), grid, block, 0, s, a);            \
+#define IA_FOCAL(T, BAL)                                                                   \
+    do {                                                                                       \
+        if (bwd && g2) hipLaunchKernelGGL((k_focal<T, true, true, BAL>), grid, block, 0, s, a);    \
+        else if (bwd) hipLaunchKernelGGL((k_focal<T, true, false, BAL>), grid, block, 0, s, a);    \
+        else if (g2) hipLaunchKernelGGL((k_focal<T, false, true, BAL>), grid, block, 0, s, a);     \
+        else hipLaunchKernelGGL((k_focal<T, false, false, BAL>), grid, block, 0, s, a);            \
     } while (0)
-    if (dtype == IA_F32) IA_FOCAL(float);
-    else if (dtype == IA_BF16) IA_FOCAL(uint16_t);
+    if (dtype == IA_F32) { if (bal) IA_FOCAL(float, true); else IA_FOCAL(float, false); }
+    else if (dtype == IA_BF16) { if (bal) IA_FOCAL(uint16_t, true); else IA_FOCAL(uint16_t, false); }
     else return IA_E_ARG;
 #undef IA_FOCAL
     return hip_status(hipGetLastError());
@@ -251,6 +283,8 @@ struct SmoothArgs {
     int32_t B, A, HW;
     float beta, gscale;
     const float *gscale_dev;
+    const float *anchor_iou;      // IoU-balanced variant (losses.py:416-458): weight * iou^delta
+    float delta;
 };
 
 // thread = (image, anchor, position); the 4 delta planes of an anchor are read coalesced along
@@ -271,7 +305,13 @@ __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
         const size_t n = ((size_t)b * HW + p) * A + an;
         const float4 tg = reinterpret_cast<const float4 *>(a.target)[n];
         const float4 wt = reinterpret_cast<const float4 *>(a.weight)[n];
-        const float tv[4] = {tg.x, tg.y, tg.z, tg.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
+        const float tv[4] = {tg.x, tg.y, tg.z, tg.w};
+        float wv[4] = {wt.x, wt.y, wt.z, wt.w};
+        if (a.anchor_iou) {                                 // exact math: equals the oracle's bits
+            const float pw = powf_pos_(a.anchor_iou[n], a.delta);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[k] = wv[k] * pw;
+        }
         const size_t e0 = (((size_t)b * A + an) * 4) * HW + p;
         const float gs = BWD ? eff_scale(a.gscale, a.gscale_dev) : 1.0f;
 #pragma unroll
@@ -294,13 +334,15 @@ __global__ void __launch_bounds__(256) k_smooth_l1(SmoothArgs a)
 
 static int launch_smooth(bool bwd, const void *pred, int dtype, const float *target,
                          const float *weight, int B, int A, int HW, float beta, float gscale,
-                         const float *gscale_dev, double *loss_sum, float *grad, hipStream_t s)
+                         const float *gscale_dev, double *loss_sum, float *grad, hipStream_t s,
+                         const float *anchor_iou = nullptr, float delta = 0.0f)
 {
     if (!pred || !target || !weight || B < 1 || A < 1 || HW < 1 || !(beta > 0.0f)) return IA_E_ARG;
     if (bwd ? !grad : !loss_sum) return IA_E_ARG;
     SmoothArgs a;
     a.pred = pred; a.target = target; a.weight = weight; a.loss_sum = loss_sum; a.grad = grad;
     a.B = B; a.A = A; a.HW = HW; a.beta = beta; a.gscale = gscale; a.gscale_dev = gscale_dev;
+    a.anchor_iou = anchor_iou; a.delta = delta;
     const int64_t blocks = (int64_t)B * A * ((HW + 255) / 256);
     if (blocks > 2147483647LL) return IA_E_ARG;
     unsigned grid = (unsigned)blocks;
@@ -559,6 +601,42 @@ int ia_smooth_l1_bwd(const void *pred, int dtype, const float *target, const flo
 {
     return ia::launch_smooth(true, pred, dtype, target, weight, B, A, HW, beta, gscale, gscale_dev,
                              nullptr, grad, (hipStream_t)stream);
+}
+int ia_focal_loss_balanced_fwd(const void *cls, int dtype, const int64_t *labels, const float *lw,
+                               const float *anchor_iou, int B, int A, int C, int HW, float gamma,
+                               float alpha, float eta, double *loss_sums3, void *stream)
+{
+    if (!anchor_iou) return IA_E_ARG;
+    return ia::launch_focal(false, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, 1.0f,
+                            nullptr, loss_sums3, nullptr, (hipStream_t)stream, anchor_iou, eta,
+                            nullptr);
+}
+int ia_focal_loss_balanced_bwd(const void *cls, int dtype, const int64_t *labels, const float *lw,
+                               const float *anchor_iou, int B, int A, int C, int HW, float gamma,
+                               float alpha, float eta, const float *normalizer_dev, float gscale,
+                               const float *gscale_dev, float *grad, void *stream)
+{
+    if (!anchor_iou) return IA_E_ARG;
+    return ia::launch_focal(true, cls, dtype, labels, lw, B, A, C, HW, gamma, alpha, gscale,
+                            gscale_dev, nullptr, grad, (hipStream_t)stream, anchor_iou, eta,
+                            normalizer_dev);
+}
+int ia_smooth_l1_balanced_fwd(const void *pred, int dtype, const float *target,
+                              const float *weight, const float *anchor_iou, int B, int A, int HW,
+                              float beta, float delta, double *loss_sum, void *stream)
+{
+    if (!anchor_iou) return IA_E_ARG;
+    return ia::launch_smooth(false, pred, dtype, target, weight, B, A, HW, beta, 1.0f, nullptr,
+                             loss_sum, nullptr, (hipStream_t)stream, anchor_iou, delta);
+}
+int ia_smooth_l1_balanced_bwd(const void *pred, int dtype, const float *target,
+                              const float *weight, const float *anchor_iou, int B, int A, int HW,
+                              float beta, float delta, float gscale, const float *gscale_dev,
+                              float *grad, void *stream)
+{
+    if (!anchor_iou) return IA_E_ARG;
+    return ia::launch_smooth(true, pred, dtype, target, weight, B, A, HW, beta, gscale, gscale_dev,
+                             nullptr, grad, (hipStream_t)stream, anchor_iou, delta);
 }
 int ia_iou_bce_fwd(const ia_head_geom *g, int level, const void *bbox_pred, const void *iou_pred,
                    int dtype, const float *bt, const float *bw, int B, float *iou_target,

@@ -61,6 +61,12 @@ SIGNATURES = {
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     'ia_smooth_l1_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    'ia_focal_loss_balanced_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp]),
+    'ia_focal_loss_balanced_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _f,
+                                        _vp, _vp, _vp]),
+    'ia_smooth_l1_balanced_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
+    'ia_smooth_l1_balanced_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp,
+                                       _vp]),
     'ia_iou_bce_fwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'ia_iou_bce_bwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     'ia_anchor_targets': (_i, [_G, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,

@@ -201,21 +201,31 @@ class IoUawareRetinaHead(AnchorHead):
                     geom=None):
         """losses of one pyramid level; each a (1,)-shaped tensor (reference :221-313).
         `level_anchor` is accepted for signature parity: anchors are regenerated in-kernel."""
-        if self.IoU_balanced_Cls or self.IoU_balanced_Loc:
-            raise NotImplementedError('IoU-balanced losses are not selected by the target configs')
         B = cls_score.shape[0]
         if geom is None:
             raise AssertionError('loss_single needs the level geometry')
         n_l = geom.level_anchors[level]
-        loss_bbox = self.loss_bbox.forward_level(bbox_pred, bbox_targets.reshape(B, n_l, 4),
-                                                 bbox_weights.reshape(B, n_l, 4), self.num_anchors,
-                                                 num_total_samples)
-        loss_iou = ops.iou_bce_sum(bbox_pred, iou_pred, bbox_targets.reshape(B, n_l, 4),
-                                   bbox_weights.reshape(B, n_l, 4), geom, level,
-                                   self.attach_iou_target) * (1.0 / num_total_samples)
-        loss_cls = self.loss_cls.forward_level(cls_score, labels.reshape(B, n_l),
-                                               label_weights.reshape(B, n_l), self.num_anchors,
-                                               num_total_samples)
+        bbox_targets, bbox_weights = bbox_targets.reshape(B, n_l, 4), bbox_weights.reshape(B, n_l, 4)
+        labels, label_weights = labels.reshape(B, n_l), label_weights.reshape(B, n_l)
+        balanced = self.IoU_balanced_Cls or self.IoU_balanced_Loc
+        # the IoU regression target (:256-259) also weights the IoU-balanced losses (detached
+        # there: losses.py:356,448)
+        out = ops.iou_bce_sum(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level,
+                              self.attach_iou_target, return_iou=balanced)
+        loss_iou, iou = (out if balanced else (out, None))
+        loss_iou = loss_iou * (1.0 / num_total_samples)
+        if self.IoU_balanced_Loc:
+            loss_bbox = self.loss_bbox.forward_level(bbox_pred, bbox_targets, bbox_weights, iou,
+                                                     self.num_anchors, num_total_samples)
+        else:
+            loss_bbox = self.loss_bbox.forward_level(bbox_pred, bbox_targets, bbox_weights,
+                                                     self.num_anchors, num_total_samples)
+        if self.IoU_balanced_Cls:
+            loss_cls = self.loss_cls.forward_level(cls_score, labels, label_weights, iou,
+                                                   self.num_anchors, num_total_samples)
+        else:
+            loss_cls = self.loss_cls.forward_level(cls_score, labels, label_weights,
+                                                   self.num_anchors, num_total_samples)
         return loss_cls, loss_bbox, loss_iou
 
     def _device_targets_ok(self, cfg, gt_bboxes, gt_bboxes_ignore, device):

@@ -73,3 +73,63 @@ class SmoothL1Loss(nn.Module):
         total = ops.smooth_l1_sum(pred.reshape(n, 4, 1, 1), target.reshape(n, 1, 4),
                                   weight.reshape(n, 1, 4), 1, self.beta)
         return total * (self.loss_weight / avg_factor)      # avg_factor: python number or device scalar
+
+
+@LOSSES.register_module
+class IOUbalancedSigmoidFocalLoss(nn.Module):
+    """reference mmdet/models/losses/iou_balanced_sigmoid_focal_loss.py:8-59; like the reference
+    the module does NOT apply loss_weight (the multiplication is commented out there, :31-42)."""
+
+    def __init__(self, use_sigmoid=False, loss_weight=1.0, gamma=2.0, alpha=0.25, eta=1.0):
+        super(IOUbalancedSigmoidFocalLoss, self).__init__()
+        if use_sigmoid is not True:
+            raise AssertionError('Only sigmoid focaloss supported now.')
+        self.use_sigmoid, self.loss_weight, self.gamma, self.alpha, self.eta = \
+            use_sigmoid, loss_weight, gamma, alpha, eta
+
+    def forward_level(self, cls_score, labels, label_weights, iou, num_anchors, avg_factor):
+        """iou (B*N_l): IoU of each anchor's predicted box with its target box (detached)."""
+        total = ops.focal_loss_balanced_sum(cls_score, labels, label_weights, iou, num_anchors,
+                                            self.gamma, self.alpha, self.eta)
+        return total * (1.0 / avg_factor)
+
+    def forward(self, cls_score, label, label_weight, iou, avg_factor=None, **kwargs):
+        """cls_score (N, C); label one-hot (N, C) or integer (N,); label_weight; iou (N,)."""
+        n, c = cls_score.shape
+        if label.dim() == 2:
+            hot = label > 0
+            label = torch.where(hot.any(1), hot.to(torch.int64).argmax(1) + 1,
+                                torch.zeros(n, dtype=torch.int64, device=label.device))
+        if label_weight.dim() == 2:
+            label_weight = label_weight[:, 0]
+        if avg_factor is None:
+            raise TypeError('avg_factor is required (the reference divides by it unconditionally, '
+                            'losses.py:374)')
+        total = ops.focal_loss_balanced_sum(cls_score.reshape(n, c, 1, 1), label, label_weight, iou,
+                                            1, self.gamma, self.alpha, self.eta)
+        return total * (1.0 / avg_factor)
+
+
+@LOSSES.register_module
+class IoUbalancedSmoothL1Loss(nn.Module):
+    """reference mmdet/models/losses/iou_balanced_smooth_l1_loss.py:8-20."""
+
+    def __init__(self, beta=1.0, delta=1.0, loss_weight=1.0):
+        super(IoUbalancedSmoothL1Loss, self).__init__()
+        self.beta, self.delta, self.loss_weight = beta, delta, loss_weight
+
+    def forward_level(self, bbox_pred, bbox_targets, bbox_weights, iou, num_anchors, avg_factor):
+        total = ops.smooth_l1_balanced_sum(bbox_pred, bbox_targets, bbox_weights, iou, num_anchors,
+                                           self.beta, self.delta)
+        return total * (self.loss_weight / avg_factor)
+
+    def forward(self, pred, target, iou, weight, avg_factor=None, **kwargs):
+        """pred / target / weight (N, 4); iou (N,)."""
+        if pred.size() != target.size() or target.numel() == 0:
+            raise AssertionError('pred / target shape mismatch or empty')
+        if avg_factor is None:
+            avg_factor = float((weight > 0).sum().item()) / 4 + 1e-6
+        n = pred.shape[0]
+        total = ops.smooth_l1_balanced_sum(pred.reshape(n, 4, 1, 1), target.reshape(n, 1, 4),
+                                           weight.reshape(n, 1, 4), iou, 1, self.beta, self.delta)
+        return total * (self.loss_weight / avg_factor)

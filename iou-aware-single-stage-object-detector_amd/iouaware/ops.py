@@ -432,7 +432,8 @@ def smooth_l1_sum(pred, target, weight, num_anchors, beta):
 
 class _IouBceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target):
+    def forward(ctx, bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target,
+                want_iou=False):
         _require_gpu(bbox_pred, 'bbox_pred')
         bbox_pred, iou_pred = bbox_pred.contiguous(), iou_pred.contiguous()
         if bbox_pred.dtype != iou_pred.dtype:
@@ -441,16 +442,22 @@ class _IouBceFn(torch.autograd.Function):
         bt = bbox_targets.contiguous().to(torch.float32)
         bw = bbox_weights.contiguous().to(torch.float32)
         acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=bbox_pred.device)
+        iou = torch.empty(iou_pred.numel(), dtype=torch.float32,
+                          device=bbox_pred.device) if want_iou else None
         _lib.check(_lib.lib().ia_iou_bce_fwd(geom.ref(), int(level), _ptr(bbox_pred), _ptr(iou_pred),
                                              _dtype_code(bbox_pred), _ptr(bt), _ptr(bw), B,
-                                             C.c_void_p(0), _ptr(acc), _stream()),
+                                             _ptr(iou), _ptr(acc), _stream()),
                    'ia_iou_bce_fwd')
         ctx.save_for_backward(bbox_pred, iou_pred, bt, bw)
         ctx.cfg = (geom, int(level), bool(attach_target))
-        return acc.sum().reshape(1).to(torch.float32)
+        loss = acc.sum().reshape(1).to(torch.float32)
+        if not want_iou:
+            return loss
+        ctx.mark_non_differentiable(iou)
+        return loss, iou
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *unused):
         bbox_pred, iou_pred, bt, bw = ctx.saved_tensors
         geom, level, attach = ctx.cfg
         B = bbox_pred.shape[0]
@@ -462,12 +469,92 @@ class _IouBceFn(torch.autograd.Function):
                                              1.0, _ptr(_gdev(g)), _ptr(g_iou), _ptr(g_box),
                                              _stream()), 'ia_iou_bce_bwd')
         return (g_box.to(bbox_pred.dtype) if attach else None, g_iou.to(iou_pred.dtype), None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def iou_bce_sum(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target=True):
+def iou_bce_sum(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level, attach_target=True,
+                return_iou=False):
+    """-> loss sum (1,), or (loss sum, iou targets (B*N_l) detached) with return_iou"""
     return _IouBceFn.apply(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level,
-                           attach_target)
+                           attach_target, return_iou)
+
+
+# ----------------------------------------------------------------- IoU-balanced variants
+class _FocalBalancedFn(torch.autograd.Function):
+    """iou_balanced_sigmoid_focal_loss (reference losses.py:309-374) summed over one level:
+    S0 + normalizer * S2, normalizer = S1 / (S2 + 1e-6) -- all on the device."""
+
+    @staticmethod
+    def forward(ctx, cls, labels, label_weights, iou, A, gamma, alpha, eta):
+        _require_gpu(cls, 'cls_score')
+        cls = cls.contiguous()
+        B, ch, H, W = cls.shape
+        Cn = ch // A
+        labels = labels.contiguous().view(-1).to(torch.int64)
+        lw = label_weights.contiguous().view(-1).to(torch.float32)
+        iou = iou.detach().contiguous().view(-1).to(torch.float32)
+        acc = torch.zeros((3, _lib.IA_LOSS_SLOTS), dtype=torch.float64, device=cls.device)
+        _lib.check(_lib.lib().ia_focal_loss_balanced_fwd(
+            _ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw), _ptr(iou), B, A, Cn, H * W,
+            float(gamma), float(alpha), float(eta), _ptr(acc), _stream()),
+            'ia_focal_loss_balanced_fwd')
+        S = acc.sum(1).to(torch.float32)
+        normalizer = (S[1] / (S[2] + 1e-6)).reshape(1).contiguous()
+        ctx.save_for_backward(cls, labels, lw, iou, normalizer)
+        ctx.cfg = (A, Cn, float(gamma), float(alpha), float(eta))
+        return (S[0] + normalizer[0] * S[2]).reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        cls, labels, lw, iou, normalizer = ctx.saved_tensors
+        A, Cn, gamma, alpha, eta = ctx.cfg
+        B, ch, H, W = cls.shape
+        grad = torch.empty(cls.shape, dtype=torch.float32, device=cls.device)
+        _lib.check(_lib.lib().ia_focal_loss_balanced_bwd(
+            _ptr(cls), _dtype_code(cls), _ptr(labels), _ptr(lw), _ptr(iou), B, A, Cn, H * W, gamma,
+            alpha, eta, _ptr(normalizer), 1.0, _ptr(_gdev(g)), _ptr(grad), _stream()),
+            'ia_focal_loss_balanced_bwd')
+        return grad.to(cls.dtype), None, None, None, None, None, None, None
+
+
+def focal_loss_balanced_sum(cls, labels, label_weights, iou, num_anchors, gamma=2.0, alpha=0.25,
+                            eta=1.5):
+    return _FocalBalancedFn.apply(cls, labels, label_weights, iou, num_anchors, gamma, alpha, eta)
+
+
+class _SmoothL1BalancedFn(torch.autograd.Function):
+    """weighted_iou_balanced_smoothl1 (reference losses.py:416-458) summed over one level."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, iou, A, beta, delta):
+        _require_gpu(pred, 'bbox_pred')
+        pred = pred.contiguous()
+        B, ch, H, W = pred.shape
+        target = target.contiguous().to(torch.float32)
+        weight = weight.contiguous().to(torch.float32)
+        iou = iou.detach().contiguous().view(-1).to(torch.float32)
+        acc = torch.zeros(_lib.IA_LOSS_SLOTS, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ia_smooth_l1_balanced_fwd(
+            _ptr(pred), _dtype_code(pred), _ptr(target), _ptr(weight), _ptr(iou), B, A, H * W,
+            float(beta), float(delta), _ptr(acc), _stream()), 'ia_smooth_l1_balanced_fwd')
+        ctx.save_for_backward(pred, target, weight, iou)
+        ctx.cfg = (A, float(beta), float(delta))
+        return acc.sum().reshape(1).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, weight, iou = ctx.saved_tensors
+        A, beta, delta = ctx.cfg
+        B, ch, H, W = pred.shape
+        grad = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.lib().ia_smooth_l1_balanced_bwd(
+            _ptr(pred), _dtype_code(pred), _ptr(target), _ptr(weight), _ptr(iou), B, A, H * W, beta,
+            delta, 1.0, _ptr(_gdev(g)), _ptr(grad), _stream()), 'ia_smooth_l1_balanced_bwd')
+        return grad.to(pred.dtype), None, None, None, None, None, None
+
+
+def smooth_l1_balanced_sum(pred, target, weight, iou, num_anchors, beta, delta):
+    return _SmoothL1BalancedFn.apply(pred, target, weight, iou, num_anchors, beta, delta)
 
 
 def iou_targets(bbox_pred, iou_pred, bbox_targets, bbox_weights, geom, level):

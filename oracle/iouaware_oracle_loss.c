@@ -262,3 +262,103 @@ void ia_o_focal_loss_op_bwd(const float *logits, const int64_t *targets, const f
             d_logits[i] = g * d_losses[i];
         }
 }
+
+/* ------------------------------------------------------------------------- */
+/* the IoU-balanced loss variants (selected by loss_cls.type =
+ * 'IOUbalancedSigmoidFocalLoss' / loss_bbox.type = 'IoUbalancedSmoothL1Loss',
+ * mmdet/models/anchor_heads/anchor_head.py:83-84; the target configs keep them in comments).  */
+
+static float ia_o_focal_elem(float x, int t, float w0, float gamma, float alpha_pos,
+                             float alpha_neg, float *g_out)
+{
+    float pr = ia_o_sigmoidf(x);
+    float pt = t ? (1.0f - pr) : pr;
+    float at = (t ? alpha_pos : alpha_neg) * w0;
+    float mod = ia_o_powf_pos(pt, gamma);
+    float W = at * mod;
+    float bce = ia_o_bce_logits(x, t ? 1.0f : 0.0f);
+    if (g_out) {
+        float dbce = pr - (t ? 1.0f : 0.0f);
+        float dpt = pr * (1.0f - pr);
+        dpt = t ? -dpt : dpt;
+        float dmod;
+        if (gamma == 2.0f) dmod = 2.0f * pt;
+        else if (gamma == 1.0f) dmod = 1.0f;
+        else if (gamma == 0.0f) dmod = 0.0f;
+        else dmod = gamma * ia_o_powf_pos(pt, gamma - 1.0f);
+        *g_out = dbce * W + (bce * at) * (dmod * dpt);
+    }
+    return bce * W;
+}
+
+/* iou_balanced_sigmoid_focal_loss (losses.py:309-374, branch IoU_balanced_Cls = True):
+ *   loss1 = focal elementwise;  w = (1 - t) + (t * iou)^eta;  normalizer = sum(loss1 t) /
+ *   (sum(loss1 w t) + 1e-6);  loss = sum(loss1 * ((1 - t) + (t iou)^eta * normalizer)), the
+ *   weights detached (:356).  Only the one positive element of a positive anchor has t = 1.
+ * iou: (B*N_l) per anchor (the IoU regression target of loss_single :256-259).
+ * sums3 = { sum over t=0 elements, S1 = sum_pos loss1, S2 = sum_pos loss1 iou^eta }.
+ * Returns S0 + normalizer * S2.                                                          */
+double ia_o_focal_loss_balanced(const float *cls, const int64_t *labels,
+                                const float *label_weights, const float *iou, int B, int A,
+                                int C, int HW, float gamma, float alpha_pos, float alpha_neg,
+                                float eta, float gscale, float *grad, double *sums3)
+{
+    double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+    const size_t Nl = (size_t)HW * A;
+    for (int pass = 0; pass < 2; ++pass) {
+        float normalizer = 0.0f;
+        if (pass == 1) {
+            normalizer = (float)S1 / ((float)S2 + 1e-6f);
+            if (!grad) break;
+        }
+        for (int b = 0; b < B; ++b)
+            for (int a = 0; a < A; ++a)
+                for (int c = 0; c < C; ++c)
+                    for (int p = 0; p < HW; ++p) {
+                        size_t e = (((size_t)b * A + a) * C + c) * HW + p;
+                        size_t n = (size_t)b * Nl + (size_t)p * A + a;
+                        int t = (labels[n] == (int64_t)(c + 1));
+                        float g;
+                        float l = ia_o_focal_elem(cls[e], t, label_weights[n], gamma, alpha_pos,
+                                                  alpha_neg, pass ? &g : NULL);
+                        if (pass == 0) {
+                            if (t) { S1 += (double)l; S2 += (double)(l * ia_o_powf_pos(iou[n], eta)); }
+                            else S0 += (double)l;
+                        } else {
+                            float w = t ? ia_o_powf_pos(iou[n], eta) * normalizer : 1.0f;
+                            grad[e] = (g * w) * gscale;
+                        }
+                    }
+    }
+    if (sums3) { sums3[0] = S0; sums3[1] = S1; sums3[2] = S2; }
+    return S0 + (double)((float)S1 / ((float)S2 + 1e-6f)) * S2;
+}
+
+/* weighted_iou_balanced_smoothl1 (losses.py:416-458): smooth-L1 with the per-anchor weight
+ * weight * iou^delta (detached).                                                          */
+double ia_o_smooth_l1_balanced(const float *pred, const float *target, const float *weight,
+                               const float *iou, int B, int A, int HW, float beta, float delta,
+                               float gscale, float *grad)
+{
+    double total = 0.0;
+    const size_t Nl = (size_t)HW * A;
+    for (int b = 0; b < B; ++b)
+        for (int a = 0; a < A; ++a)
+            for (int k = 0; k < 4; ++k)
+                for (int p = 0; p < HW; ++p) {
+                    size_t e = (((size_t)b * A + a) * 4 + k) * HW + p;
+                    size_t r = (size_t)b * Nl + (size_t)p * A + a;
+                    size_t n = r * 4 + k;
+                    float df = pred[e] - target[n];
+                    float d = fabsf(df);
+                    float l = (d < beta) ? ((0.5f * d) * d) / beta : d - 0.5f * beta;
+                    float w = weight[n] * ia_o_powf_pos(iou[r], delta);           /* :447 */
+                    total += (double)(l * w);
+                    if (grad) {
+                        float s = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
+                        float g = (d < beta) ? df / beta : s;
+                        grad[e] = (g * w) * gscale;
+                    }
+                }
+    return total;
+}

@@ -269,3 +269,38 @@ def vec_exp_f64(x):
     dp = C.POINTER(C.c_double)
     lib().ia_o_vec_exp_f64(x.ctypes.data_as(dp), y.ctypes.data_as(dp), C.c_longlong(x.size))
     return y
+
+
+# ------------------------------------------------------------------ IoU-balanced losses (8f.4)
+def focal_loss_balanced(cls, labels, label_weights, iou, A, gamma=2.0, alpha=0.25, eta=1.5,
+                        gscale=None):
+    """iou_balanced_sigmoid_focal_loss (losses.py:309-374) on NCHW logits.
+    -> (sum, grad or None, sums3 = [S0, S1, S2])"""
+    cls = _f(cls)
+    B, ch, H, W = cls.shape
+    Cn = ch // A
+    labels = np.ascontiguousarray(labels, np.int64).reshape(-1)
+    lw, iou = _f(label_weights).reshape(-1), _f(iou).reshape(-1)
+    grad = np.empty_like(cls) if gscale is not None else None
+    sums = np.zeros(3, np.float64)
+    fn = lib().ia_o_focal_loss_balanced
+    fn.restype = C.c_double
+    s = fn(_fp(cls), _i64p(labels), _fp(lw), _fp(iou), B, A, Cn, H * W, C.c_float(gamma),
+           C.c_float(alpha), C.c_float(np.float32(1.0 - alpha)), C.c_float(eta),
+           C.c_float(0.0 if gscale is None else gscale), _fp(grad) if grad is not None else None,
+           sums.ctypes.data_as(C.POINTER(C.c_double)))
+    return s, grad, sums
+
+
+def smooth_l1_balanced(pred, target, weight, iou, A, beta, delta, gscale=None):
+    """weighted_iou_balanced_smoothl1 (losses.py:416-458) -> (sum, grad or None)"""
+    pred = _f(pred)
+    B, ch, H, W = pred.shape
+    target, weight, iou = _f(target), _f(weight), _f(iou).reshape(-1)
+    grad = np.empty_like(pred) if gscale is not None else None
+    fn = lib().ia_o_smooth_l1_balanced
+    fn.restype = C.c_double
+    s = fn(_fp(pred), _fp(target), _fp(weight), _fp(iou), B, A, H * W, C.c_float(beta),
+           C.c_float(delta), C.c_float(0.0 if gscale is None else gscale),
+           _fp(grad) if grad is not None else None)
+    return s, grad

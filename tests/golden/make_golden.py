@@ -392,6 +392,49 @@ def gen_losses():
 
 
 
+# ---------------------------------------------------------------- IoU-balanced losses (8f.4)
+def gen_losses_balanced():
+    """head.loss with loss_cls = IOUbalancedSigmoidFocalLoss(eta=1.5) and loss_bbox =
+    IoUbalancedSmoothL1Loss(beta=0.11, delta=1.5, loss_weight=3.049) -- the values the target
+    configs keep in comments -- on the inputs of losses_small (same targets)."""
+    kw = dict(HEAD_KW)
+    kw['loss_cls'] = dict(type='IOUbalancedSigmoidFocalLoss', use_sigmoid=True, gamma=2.0,
+                          alpha=0.25, eta=1.5, loss_weight=1.0)
+    kw['loss_bbox'] = dict(type='IoUbalancedSmoothL1Loss', beta=0.11, delta=1.5, loss_weight=3.049)
+    head = IoUawareRetinaHead(**kw)
+    assert head.IoU_balanced_Cls and head.IoU_balanced_Loc
+    train_cfg = ref_shim.to_cfg(dict(
+        assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
+                      ignore_iof_thr=-1),
+        allowed_border=-1, pos_weight=-1, debug=False))
+    seed, B, ih, iw, ph, pw = 303, 2, 120, 157, 128, 160
+    cls, reg, iou = synth.head_outputs(seed, B, ph, pw, 'A')
+    gts, gls = synth.train_targets(seed + 1, B, ih, iw)
+    metas = [synth.img_meta(ih, iw, ph, pw, 1.0) for _ in range(B)]
+    out = dict(seed=seed, batch=B, img=np.array([ih, iw, ph, pw]), kind='A',
+               checksum=synth.checksum(cls + reg + iou), eta=np.float32(1.5),
+               delta=np.float32(1.5), beta=np.float32(0.11), bbox_loss_weight=np.float32(3.049))
+    tc = [torch.from_numpy(x).requires_grad_(True) for x in cls]
+    tr = [torch.from_numpy(x).requires_grad_(True) for x in reg]
+    ti = [torch.from_numpy(x).requires_grad_(True) for x in iou]
+    losses = head.loss(tc, tr, ti, [torch.from_numpy(g) for g in gts],
+                       [torch.from_numpy(g) for g in gls], metas, train_cfg)
+    sum(sum(v) for v in losses.values()).backward()
+    for k, v in losses.items():
+        out[k] = np.array([float(x) for x in v], np.float64)
+    rs = np.random.RandomState(98)
+    for l in range(5):
+        for nm, tl in (('cls', tc), ('reg', tr), ('iou', ti)):
+            g = tl[l].grad.numpy().reshape(-1)
+            key = 'g_%s_%d' % (nm, l)
+            out[key + '_idx'] = rs.choice(g.size, min(g.size, 3000), replace=False).astype(np.int64)
+            out[key] = g[out[key + '_idx']]
+            out[key + '_sum'] = np.float64(g.astype(np.float64).sum())
+            out[key + '_abs'] = np.float64(np.abs(g.astype(np.float64)).sum())
+    print('balanced losses', {k: out[k] for k in ('loss_cls', 'loss_bbox', 'losses_iou')})
+    save('losses_balanced', **out)
+
+
 # ---------------------------------------------------------------- model structure (B1, I3)
 def gen_model():
     """parameter names / shapes of the four reference configs (+ the 64x4d backbone of BASELINE
@@ -414,6 +457,6 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'model']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model']
     for w in which:
         globals()['gen_' + w]()

@@ -175,3 +175,70 @@ def test_loss_module_signatures_on_permuted_inputs(ops, oracle_lib, fx):
     bw = torch.from_numpy(f['bbox_weights_0']).cuda().reshape(-1, 4)
     got = SmoothL1Loss(beta=0.11)(pred, bt, bw, avg_factor=avg)
     assert abs(float(got) - f['loss_bbox'][0]) <= 1e-4 * f['loss_bbox'][0]
+
+
+# ------------------------------------------------------------------ IoU-balanced variants (8f.4)
+def test_iou_balanced_losses_vs_oracle(ops, oracle_lib, fx):
+    f, cls, reg, iou, B, (ph, pw) = fx
+    geom, base = G.geometry(ph, pw, -1)
+    gs = float(np.float32(1.0 / float(f['num_total_pos'])))
+    for l, (h, w) in enumerate(geom.featmap_sizes):
+        n_l = h * w * synth.A
+        labels = torch.from_numpy(f['labels_%d' % l]).cuda()
+        lw = torch.from_numpy(f['label_weights_%d' % l]).cuda()
+        bt = torch.from_numpy(f['bbox_targets_%d' % l]).cuda().reshape(B, n_l, 4)
+        bw = torch.from_numpy(f['bbox_weights_%d' % l]).cuda().reshape(B, n_l, 4)
+        c = torch.from_numpy(cls[l]).cuda().requires_grad_(True)
+        r = torch.from_numpy(reg[l]).cuda().requires_grad_(True)
+        i = torch.from_numpy(iou[l]).cuda()
+        _, tgt = ops.iou_bce_sum(r.detach(), i, bt, bw, geom, l, True, return_iou=True)
+        _, otgt, _, _ = oracle_lib.iou_bce(reg[l], iou[l], f['bbox_targets_%d' % l],
+                                           f['bbox_weights_%d' % l], base[l], synth.STRIDES[l])
+        assert G.same_bits(tgt.cpu().numpy(), otgt)
+        lc = ops.focal_loss_balanced_sum(c, labels, lw, tgt, synth.A, 2.0, 0.25, 1.5) * gs
+        lb = ops.smooth_l1_balanced_sum(r, bt, bw, tgt, synth.A, 0.11, 1.5) * gs
+        (lc + lb).sum().backward()
+        so, go, sums = oracle_lib.focal_loss_balanced(cls[l], f['labels_%d' % l],
+                                                      f['label_weights_%d' % l], otgt, synth.A,
+                                                      2.0, 0.25, 1.5, gscale=gs)
+        assert rel(float(lc) / gs, so) < 1e-5, (l, float(lc) / gs, so)
+        gd = c.grad.cpu().numpy().astype(np.float64)
+        assert (np.abs(gd - go) <= 2e-5 * np.abs(go) + 2e-6 * np.abs(go).max()).all(), l
+        sb, gb = oracle_lib.smooth_l1_balanced(reg[l], f['bbox_targets_%d' % l],
+                                               f['bbox_weights_%d' % l], otgt, synth.A, 0.11, 1.5,
+                                               gscale=gs)
+        assert abs(float(lb) / gs - sb) <= 1e-6 * max(abs(sb), 1e-6)
+        assert G.same_bits(r.grad.cpu().numpy(), gb), 'balanced smooth-L1 grad level %d' % l
+
+
+def test_head_loss_iou_balanced_vs_reference(ops, fx, golden_dir):
+    """loss_cls.type='IOUbalancedSigmoidFocalLoss', loss_bbox.type='IoUbalancedSmoothL1Loss'
+    through IoUawareRetinaHead.loss against the reference's own output."""
+    from iouaware.head import IoUawareRetinaHead
+    from test_host_targets import HEAD_KW, TRAIN_CFG
+    f, cls, reg, iou, B, (ph, pw) = fx
+    fb = np.load(os.path.join(golden_dir, 'losses_balanced.npz'))
+    kw = dict(HEAD_KW)
+    kw['loss_cls'] = dict(type='IOUbalancedSigmoidFocalLoss', use_sigmoid=True, gamma=2.0,
+                          alpha=0.25, eta=1.5, loss_weight=1.0)
+    kw['loss_bbox'] = dict(type='IoUbalancedSmoothL1Loss', beta=0.11, delta=1.5, loss_weight=3.049)
+    head = IoUawareRetinaHead(**kw).cuda()
+    assert head.IoU_balanced_Cls and head.IoU_balanced_Loc and not head.sampling
+    ih, iw = int(f['img'][0]), int(f['img'][1])
+    metas = [synth.img_meta(ih, iw, ph, pw) for _ in range(B)]
+    gts = [torch.from_numpy(f['gt_bboxes_%d' % b]).cuda() for b in range(B)]
+    gls = [torch.from_numpy(f['gt_labels_%d' % b]).cuda() for b in range(B)]
+    c = [t.requires_grad_(True) for t in G.to_dev(cls)]
+    r = [t.requires_grad_(True) for t in G.to_dev(reg)]
+    i = [t.requires_grad_(True) for t in G.to_dev(iou)]
+    losses = head.loss(c, r, i, gts, gls, metas, TRAIN_CFG)
+    for k in losses:
+        got = np.array([float(x) for x in losses[k]])
+        assert np.all(np.abs(got - fb[k]) <= 1e-4 * np.maximum(np.abs(fb[k]), 1e-6)), (k, got, fb[k])
+    sum(sum(v) for v in losses.values()).backward()
+    for l in range(5):
+        for key, g in (('g_cls_%d' % l, c[l].grad), ('g_reg_%d' % l, r[l].grad),
+                       ('g_iou_%d' % l, i[l].grad)):
+            want = fb[key].astype(np.float64)
+            got = g.cpu().numpy().reshape(-1)[fb[key + '_idx']].astype(np.float64)
+            assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), key

@@ -80,3 +80,38 @@ def test_focal_op_formula_against_float64(oracle_lib):
              * alpha - c2 * p ** gamma * (lg2 * (1 - p) * gamma - p) * (1 - alpha)) * dl
     ggot = oracle_lib.focal_loss_op(x, t, gamma, alpha, dl)
     assert np.abs(ggot - gwant).max() <= 1e-5 * max(1.0, np.abs(gwant).max())
+
+
+def test_iou_balanced_losses_match_reference(oracle_lib, fx, golden_dir):
+    """IOUbalancedSigmoidFocalLoss(eta=1.5) + IoUbalancedSmoothL1Loss(delta=1.5,
+    loss_weight=3.049) through the reference head (tests/golden/losses_balanced.npz); targets are
+    those of losses_small (same inputs)."""
+    f, cls, reg, iou, B, shapes = fx
+    fb = np.load(os.path.join(golden_dir, 'losses_balanced.npz'))
+    assert int(fb['checksum']) == int(f['checksum'])
+    base = oracle_lib.head_base_anchors(synth.STRIDES)
+    avg = float(f['num_total_pos'])
+    eta, delta, lwt = float(fb['eta']), float(fb['delta']), float(fb['bbox_loss_weight'])
+
+    def gclose(g, key, tol=2e-4):
+        want = fb[key].astype(np.float64)
+        got = g.reshape(-1)[fb[key + '_idx']].astype(np.float64)
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(got - want).max() <= tol * scale, (key, np.abs(got - want).max(), scale)
+        assert rel(np.abs(g.astype(np.float64)).sum(), float(fb[key + '_abs'])) < 2e-4
+
+    for l, (h, w) in enumerate(shapes):
+        labels, lw = f['labels_%d' % l].reshape(-1), f['label_weights_%d' % l].reshape(-1)
+        bt, bw = f['bbox_targets_%d' % l].reshape(-1, 4), f['bbox_weights_%d' % l].reshape(-1, 4)
+        s2, tgt, g_iou, g_box = oracle_lib.iou_bce(reg[l], iou[l], bt, bw, base[l],
+                                                   synth.STRIDES[l], gscale=1.0 / avg)
+        s, g, sums = oracle_lib.focal_loss_balanced(cls[l], labels, lw, tgt, synth.A, 2.0, 0.25,
+                                                    eta, gscale=1.0 / avg)
+        assert rel(s / avg, fb['loss_cls'][l]) < 1e-4
+        gclose(g, 'g_cls_%d' % l)
+        sb, gb = oracle_lib.smooth_l1_balanced(reg[l], bt, bw, tgt, synth.A, 0.11, delta,
+                                               gscale=lwt / avg)
+        assert abs(sb * lwt / avg - fb['loss_bbox'][l]) <= 1e-4 * max(fb['loss_bbox'][l], 1e-6)
+        assert abs(s2 / avg - fb['losses_iou'][l]) <= 1e-4 * max(fb['losses_iou'][l], 1e-6)
+        gclose(gb + g_box, 'g_reg_%d' % l)
+        gclose(g_iou, 'g_iou_%d' % l)

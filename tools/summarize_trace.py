@@ -1,6 +1,6 @@
 """Reduce a rocprofv3 --kernel-trace CSV to a per-step kernel summary.
 
-A benchmark step ends with ia::k_finalize; everything between two consecutive
+A benchmark step ends with ia::k_finalize (not k_finalize_part); everything between two consecutive
 k_finalize completions is one step.  MIOpen find-mode trials (first steps) are
 excluded by summarising only the last `--steps` steps.
 
@@ -15,7 +15,7 @@ import sys
 ap = argparse.ArgumentParser()
 ap.add_argument('trace')
 ap.add_argument('--steps', type=int, default=5)
-ap.add_argument('--marker', default='k_finalize')
+ap.add_argument('--marker', default='ia::k_finalize(')
 ap.add_argument('--top', type=int, default=45)
 args = ap.parse_args()
 
