@@ -153,6 +153,21 @@ int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *coun
 int ia_soft_nms(const float *dets, int n, float iou_thr, int method, float sigma, float min_score,
                 float *out_dets, int32_t *out_inds, int32_t *count, void *stream);
 
+/* Image pre-processing in front of the backbone: ImageTransform.__call__
+ * (mmdet/datasets/transforms.py:31-50): cv2 bilinear resize of the uint8 BGR image to
+ * (dst_h, dst_w) (the caller computes the size like mmcv.imrescale / imresize), BGR->RGB,
+ * (x - mean) / std, horizontal flip, zero padding to (pad_h, pad_w), HWC->CHW; one launch
+ * per <= 16 images.  imgs: HOST array of descriptors whose src pointers are DEVICE uint8
+ * (src_h, src_w, 3) images.  out: (B,3,pad_h,pad_w) fp32, or (B,pad_h,pad_w,3) when
+ * channels_last (the memory layout of a channels-last (B,3,H,W) tensor).              */
+typedef struct {
+    const uint8_t *src;
+    int32_t src_h, src_w, dst_h, dst_w, flip;
+} ia_image_desc;
+int ia_image_transform(const ia_image_desc *imgs, int batch, const float *mean, const float *std,
+                       int to_rgb, int pad_h, int pad_w, int channels_last, float *out,
+                       void *stream);
+
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on
  * the NCHW head outputs directly.  Each *_fwd ADDS its fp64 partial sums into

@@ -11,5 +11,6 @@ from .registry import (BACKBONES, DETECTORS, HEADS, LOSSES, NECKS, Registry,  # 
                        build_backbone, build_detector, build_head, build_loss, build_neck)
 from . import backbones, fpn, losses, head, detectors                   # noqa: F401  (register)
 from .api import init_detector, inference_batch                         # noqa: F401
+from .preprocess import ImageTransform                                  # noqa: F401
 
 __version__ = '0.1.0'

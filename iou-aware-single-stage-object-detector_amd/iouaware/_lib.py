@@ -33,6 +33,11 @@ class LevelPtrs(C.Structure):
                 ('iou', C.c_void_p * IA_MAX_LEVELS)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('src_h', C.c_int32), ('src_w', C.c_int32),
+                ('dst_h', C.c_int32), ('dst_w', C.c_int32), ('flip', C.c_int32)]
+
+
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 _G, _P = C.POINTER(HeadGeom), C.POINTER(LevelPtrs)
 
@@ -57,6 +62,8 @@ SIGNATURES = {
     'ia_get_bboxes_workspace_layout': (_i, [_G, _i, C.POINTER(_sz * 8)]),
     'ia_nms_workspace_bytes': (_sz, [_i]),
     'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'ia_image_transform': (_i, [C.POINTER(ImageDesc), _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                _i, _i, _i, _i, _vp, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

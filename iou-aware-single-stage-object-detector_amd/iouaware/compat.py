@@ -29,7 +29,7 @@ def install(force=False):
             return existing
         raise RuntimeError('a different `mmdet` is already imported')
     from . import (anchors, api, bbox, detectors, fpn, head, layers, losses, nms_op, registry,
-                   targets, backbones, dist as idist, focal_op)
+                   targets, backbones, dist as idist, focal_op, preprocess)
     root = _mod('mmdet', __version__='0.6.0+iouaware', __iouaware__=True)
     models = _mod('mmdet.models', **{k: getattr(registry, k) for k in (
         'BACKBONES', 'NECKS', 'ROI_EXTRACTORS', 'SHARED_HEADS', 'HEADS', 'LOSSES', 'DETECTORS',
@@ -50,7 +50,9 @@ def install(force=False):
                             SingleStageDetector=detectors.SingleStageDetector,
                             RetinaNet=detectors.RetinaNet)
     models.losses = _mod('mmdet.models.losses', FocalLoss=losses.FocalLoss,
-                         SmoothL1Loss=losses.SmoothL1Loss)
+                         SmoothL1Loss=losses.SmoothL1Loss,
+                         IOUbalancedSigmoidFocalLoss=losses.IOUbalancedSigmoidFocalLoss,
+                         IoUbalancedSmoothL1Loss=losses.IoUbalancedSmoothL1Loss)
     models.utils = _mod('mmdet.models.utils', **{k: getattr(layers, k) for k in (
         'ConvModule', 'build_conv_layer', 'build_norm_layer', 'xavier_init', 'normal_init',
         'uniform_init', 'kaiming_init', 'bias_init_with_prob')})
@@ -85,5 +87,7 @@ def install(force=False):
 
     apis = _mod('mmdet.apis', init_dist=idist.init_dist, init_detector=api.init_detector,
                 get_dist_info=idist.get_dist_info)
-    root.models, root.ops, root.core, root.apis = models, mops, core, apis
+    datasets = _mod('mmdet.datasets', ImageTransform=preprocess.ImageTransform)
+    datasets.transforms = _mod('mmdet.datasets.transforms', ImageTransform=preprocess.ImageTransform)
+    root.models, root.ops, root.core, root.apis, root.datasets = models, mops, core, apis, datasets
     return root

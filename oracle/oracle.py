@@ -19,7 +19,7 @@ _i32p = C.POINTER(C.c_int32)
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in
-            ('iouaware_oracle.c', 'iouaware_oracle_loss.c', 'iouaware_oracle_softnms.c',
+            ('iouaware_oracle.c', 'iouaware_oracle_loss.c', 'iouaware_oracle_softnms.c', 'iouaware_oracle_preproc.c',
              'ia_oracle_math.h', 'Makefile')]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
@@ -304,3 +304,45 @@ def smooth_l1_balanced(pred, target, weight, iou, A, beta, delta, gscale=None):
            C.c_float(delta), C.c_float(0.0 if gscale is None else gscale),
            _fp(grad) if grad is not None else None)
     return s, grad
+
+
+# ------------------------------------------------------------------ image pre-processing (8f.3)
+def rescale_size(h, w, scale, keep_ratio=True):
+    """mmcv.imrescale / imresize sizes (mmcv 0.2.x image/transforms/resize.py, restated):
+    -> (new_h, new_w, scale_factor) ; scale_factor a python float (keep_ratio) or a
+    (w_scale, h_scale, w_scale, h_scale) fp32 array."""
+    if keep_ratio:
+        max_long, max_short = max(scale), min(scale)
+        sf = min(max_long / max(h, w), max_short / min(h, w))
+        return int(h * float(sf) + 0.5), int(w * float(sf) + 0.5), sf
+    nw, nh = scale
+    return nh, nw, np.array([nw / w, nh / h, nw / w, nh / h], np.float32)
+
+
+def resize_bilinear_u8(img, nh, nw):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    assert c == 3
+    out = np.empty((nh, nw, 3), np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().ia_o_resize_bilinear_u8(img.ctypes.data_as(u8), h, w, out.ctypes.data_as(u8), nh, nw)
+    return out
+
+
+def image_transform(img, scale, flip=False, keep_ratio=True, mean=(0, 0, 0), std=(1, 1, 1),
+                    to_rgb=True, size_divisor=None):
+    """ImageTransform.__call__ (mmdet/datasets/transforms.py:31-50)
+    -> (img (3,ph,pw) fp32, img_shape, pad_shape, scale_factor)"""
+    h, w = img.shape[:2]
+    nh, nw, sf = rescale_size(h, w, scale, keep_ratio)
+    r = resize_bilinear_u8(img, nh, nw)
+    if size_divisor is not None:
+        ph = int(np.ceil(nh / size_divisor)) * size_divisor
+        pw = int(np.ceil(nw / size_divisor)) * size_divisor
+    else:
+        ph, pw = nh, nw
+    out = np.empty((3, ph, pw), np.float32)
+    u8 = C.POINTER(C.c_uint8)
+    lib().ia_o_normalize_flip_pad_chw(r.ctypes.data_as(u8), nh, nw, _fp(_f(mean)), _fp(_f(std)),
+                                      int(bool(to_rgb)), int(bool(flip)), ph, pw, _fp(out))
+    return out, (nh, nw, 3), (ph, pw, 3), sf
