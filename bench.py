@@ -61,14 +61,16 @@ TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nm
                 max_per_img=100)
 
 
-def build_model(device, fuse=True, channels_last=False):
+def build_model(device, fuse=True, channels_last=False, winograd=True):
     torch.manual_seed(0)
     model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=None,
                                     test_cfg=ConfigDict(TEST_CFG))
     model = model.to(device).eval()
     if fuse:
         from iouaware.fuse import fuse_inference
-        fuse_inference(model)       # conv epilogues (BN / bias / add / ReLU) -> one HIP pass each
+        # conv epilogues (BN / bias / add / ReLU) -> one HIP pass each; the head's 3x3 convs ->
+        # Winograd F(4x4,3x3) transforms (HIP) around one batched fp32 GEMM per layer
+        fuse_inference(model, winograd=winograd and channels_last)
     if channels_last:
         # MIOpen's fp32 NHWC implicit-GEMM kernels beat the NCHW Winograd path on this net
         # (tools/try_layouts.py); the three head outputs are brought back to NCHW by
@@ -92,6 +94,7 @@ class Stepper(object):
         self.rowmax_ms = []
         self.pending = []
         self.last = None
+        self.nhwc = False
 
     @torch.no_grad()
     def step(self, timed=False):
@@ -103,10 +106,10 @@ class Stepper(object):
         factors = [x['scale_factor'] for x in self.metas]
         if timed:
             # same kernels as ops.get_bboxes, launched stage by stage so that HIP events on the
-            # launch stream bracket k_rowmax alone (layout conversion first, outside the events)
-            cls = [ops.to_nchw(t) for t in cls]
-            reg = [ops.to_nchw(t) for t in reg]
-            iou = [ops.to_nchw(t) for t in iou]
+            # launch stream bracket the row-max kernel alone.  Channels-last head outputs are
+            # consumed in place (k_rowmax_nhwc); NCHW ones by k_rowmax.
+            geom = ops.geometry_for(geom, cls, reg, iou)
+            self.nhwc = bool(geom.layout)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
@@ -168,7 +171,7 @@ def cpu_baseline(model, stepper):
                                       os.cpu_count()))
 
 
-def rowmax_traffic():
+def rowmax_traffic(kernel):
     """HBM bytes per k_rowmax launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 correction 2 x FETCH_SIZE; tools/collect_pmc.sh).  It is a
     batch-8 launch like the benchmark's; None when the profile is missing."""
@@ -178,7 +181,7 @@ def rowmax_traffic():
             prof = json.load(f)
         if prof.get('batch') != BATCH:
             return None
-        return int(prof['kernels']['ia::k_rowmax<float>']['traffic_bytes_per_launch'])
+        return int(prof['kernels'][kernel]['traffic_bytes_per_launch'])
     except Exception:
         return None
 
@@ -191,6 +194,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
     ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
+    ap.add_argument('--no-winograd', action='store_true',
+                    help='head 3x3 convolutions through MIOpen instead of the Winograd path')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -205,7 +210,8 @@ def main():
         dist.init_process_group(backend='nccl')
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
 
-    model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw)
+    model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw,
+                        winograd=not args.no_winograd)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     imgs = torch.randn(BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
     if not args.nchw:
@@ -237,6 +243,8 @@ def main():
     if rank == 0:
         n_img = BATCH * world * args.steps
         ms_rowmax = float(np.mean(stepper.rowmax_ms))
+        # the row-max kernel that ran: channels-last head outputs -> k_rowmax_nhwc<float, 20>
+        rm_kernel = 'ia::k_rowmax_nhwc<float, 20>' if stepper.nhwc else 'ia::k_rowmax<float>'
         achieved = HEAD_BYTES_PER_IMAGE * BATCH / (ms_rowmax * 1e-3) / 1e9
         out = {
             'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN',
@@ -249,9 +257,10 @@ def main():
                                    'whole inference path incl. NMS',
                        'global_batch': BATCH * world, 'parallelism': 'dp%d' % world,
                        'dets_per_image': int(stepper.last[2].float().mean().item())},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_rowmax', 'achieved': round(achieved, 1),
+            'roofline': {'bound': 'hbm', 'kernel': rm_kernel.split('::')[1].split('<')[0],
+                         'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': rowmax_traffic(),
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': rowmax_traffic(rm_kernel),
                          'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
                          'avg_launch_ms': round(ms_rowmax, 4)},
         }

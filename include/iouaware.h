@@ -11,9 +11,12 @@
  *     *_workspace_bytes() query.  Calls are asynchronous on `stream`.
  *   - return value: 0 = ok, negative = IA_E_* argument error, positive =
  *     hipError_t of a failed launch.
- *   - feature maps are NCHW, contiguous, dtype IA_F32 or IA_BF16; channel
- *     a*C+c (cls), a*4+k (reg), a (iou) -- the reference head's output layout
- *     (reference mmdet/models/anchor_heads/iou_aware_retina_head.py:171-219).
+ *   - feature maps are (B, ch, H, W) tensors, dtype IA_F32 or IA_BF16, channel
+ *     a*C+c (cls), a*4+k (reg), a (iou) -- the reference head's output
+ *     (reference mmdet/models/anchor_heads/iou_aware_retina_head.py:171-219) -- stored
+ *     contiguously either NCHW or channels-last (memory (B, H, W, ch), what MIOpen's
+ *     NHWC convolutions write: exactly the reference's permute(0,2,3,1) view, :502-507);
+ *     ia_head_geom.layout says which.  The training kernels take NCHW only.
  *
  * Each entry point names the reference interface it replaces (paths relative
  * to the reference repository root).
@@ -37,6 +40,9 @@ extern "C" {
 #define IA_F32 0
 #define IA_BF16 1
 
+#define IA_LAYOUT_NCHW 0
+#define IA_LAYOUT_NHWC 1     /* needs C * sizeof(dtype) to be a multiple of 16, <= 512 bytes */
+
 #define IA_LOSS_SLOTS 64     /* partial sums written by the *_fwd loss kernels */
 
 #define IA_E_ARG (-1)        /* invalid argument / unsupported size */
@@ -53,6 +59,7 @@ typedef struct ia_head_geom {
     int32_t stride[IA_MAX_LEVELS];
     float base_anchors[IA_MAX_LEVELS][IA_MAX_ANCHORS][4];  /* AnchorGenerator.base_anchors */
     float means[4], stds[4];            /* target_means / target_stds */
+    int32_t layout;                     /* IA_LAYOUT_*: memory order of the head outputs */
 } ia_head_geom;
 
 /* Per-level device pointers of the three head outputs, each (B, ch, H, W). */
@@ -76,7 +83,8 @@ const char *ia_version(void);
 /* iou_aware_retina_head.py:502-531,539: per anchor max over classes of
  * sqrt(sigmoid(cls)) * sqrt(sigmoid(iou)).  rowmax: (B, N) fp32; inside an image
  * each level is an (A, H*W) block (anchor-major), i.e. element a*HW + p holds the
- * reference's anchor index p*A + a.                                            */
+ * reference's anchor index p*A + a (IA_LAYOUT_NCHW), or the reference's own order
+ * p*A + a (IA_LAYOUT_NHWC).  ia_select_topk reads whichever g->layout implies.   */
 int ia_decode_fuse_rowmax(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                           float *rowmax, void *stream);
 
@@ -167,6 +175,32 @@ typedef struct {
 int ia_image_transform(const ia_image_desc *imgs, int batch, const float *mean, const float *std,
                        int to_rgb, int pad_h, int pad_w, int channels_last, float *out,
                        void *stream);
+
+/* Winograd F(4x4,3x3) transforms around a library batched GEMM, for the 3x3 / stride-1 / pad-1
+ * convolutions of the head towers and outputs (iou_aware_retina_head.py:171-219; replaces
+ * ConvModule.forward, mmdet/models/utils/conv_module.py:149-163, and the three output
+ * nn.Conv2d) and of the FPN outputs (mmdet/models/necks/fpn.py:124-127) at inference.
+ * All pyramid levels of a batch form ONE tile list (tiles of 4x4 outputs, level-major, then
+ * image, then row-major), so a shared-weight layer is one batched GEMM:
+ *   V (groups*36, T, C/groups)  = input transform of channels-last activations (B,H_l,W_l,C)
+ *   M[k] = V[k] . U[k]          (caller: rocBLAS / hipBLASLt; U = G g G^T, (36, Cin, Cout))
+ *   output transform of M (groups*36, T, C/groups) + bias (+ ReLU) -> channel ranges
+ *   ("segments") of channels-last destination tensors.                                   */
+typedef struct {
+    int32_t num_levels, batch;
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS];
+} ia_wino_geom;
+typedef struct {
+    int32_t c0, n;                  /* output channels [c0, c0+n) of the GEMM result ...   */
+    int32_t dst_channels, dst_offset;   /* ... go to channels [dst_offset, +n) of dst     */
+    float *dst[IA_MAX_LEVELS];      /* per level (B, H_l, W_l, dst_channels)               */
+} ia_wino_seg;
+int ia_wino_tiles(const ia_wino_geom *g, int32_t *tiles);
+int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int channels, int groups,
+                            float *V, void *stream);
+int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels, int groups,
+                             const float *bias, int relu, int nseg, const ia_wino_seg *segs,
+                             void *stream);
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on

@@ -134,11 +134,113 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
         if (pos[j] < HW) out[pos[j]] = sqrt_sigmoidf_(m[j]) * sqrt_sigmoidf_(il[j]);
 }
 
+// ---------------------------------------------------------------------------
+// Channels-last head outputs (what MIOpen's NHWC convolutions write): a level is one flat
+// array of B*HW*A rows of C contiguous logits -- the reference's own
+// permute(0,2,3,1).reshape(-1, C) view (:502-507) without the copy.  One wavefront takes 64
+// consecutive rows = one contiguous 64*C*sizeof(T)-byte run (20 KiB for C = 80 fp32) with VPR
+// fully coalesced, non-temporal 16-byte loads per lane (1 KiB per instruction); lane maxima
+// are transposed through LDS (row stride VPR+1: conflict-free) so that lane r reduces row r,
+// and the row maxima are stored in row order p*A + a, 256 B per wavefront.
+struct RowmaxNhwcArgs {
+    LevelTable t;
+    ia_level_ptrs p;
+    float *rowmax;
+    int32_t blk_off[IA_MAX_LEVELS + 1];   // prefix of ceil(B * N_l / 64), levels in REVERSE order
+    int32_t batch, anchors_per_img;
+};
+
+constexpr int kMaxVpr = 32;              // 16-byte vectors per row: C * sizeof(T) <= 512 bytes
+
+template <typename T, int VPR_T>         // VPR_T = 0: run-time vectors per row
+__global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
+{
+    constexpr int PPL = Lane<T>::PPL;
+    __shared__ float s_m[64 * ((VPR_T ? VPR_T : kMaxVpr) + 1)];
+    const int lane = threadIdx.x;
+    const int L = a.t.num_levels;
+    int rem = blockIdx.x, rl = 0;
+    while (rem >= a.blk_off[rl + 1]) ++rl;
+    rem -= a.blk_off[rl];
+    const int l = L - 1 - rl;
+    const int vpr = VPR_T ? VPR_T : a.t.C / PPL;
+    const int n_l = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
+    const int64_t rows = (int64_t)a.batch * n_l;
+    const int64_t r0 = (int64_t)rem * 64;
+    const int nrow = (rows - r0 < 64) ? (int)(rows - r0) : 64;
+    const int nvec = nrow * vpr;
+    const T *src = static_cast<const T *>(a.p.cls[l]) + r0 * a.t.C;
+    // this lane's row: its IoU logit is requested first so that its latency hides behind the
+    // class loads instead of following the barrier
+    const int64_t g = r0 + ((lane < nrow) ? lane : (nrow - 1));
+    const float il = load_f32<T>(static_cast<const T *>(a.p.iou[l]) + g);
+    auto body = [&](int k) {
+        const int f = k * 64 + lane;
+        const int fc = (f < nvec) ? f : (nvec - 1);             // loads are never predicated
+        float v[PPL];
+        Lane<T>::load(src + (size_t)fc * PPL, v);
+        float m = v[0];
+#pragma unroll
+        for (int j = 1; j < PPL; ++j) m = (m < v[j]) ? v[j] : m;
+        const int row = f / vpr, c4 = f - row * vpr;
+        if (f < nvec) s_m[row * (vpr + 1) + c4] = m;
+    };
+    if (VPR_T) {
+#pragma unroll
+        for (int k = 0; k < VPR_T; ++k) body(k);
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < vpr; ++k) body(k);
+    }
+    __syncthreads();
+    if (lane < nrow) {
+        const float *sr = s_m + lane * (vpr + 1);
+        float m = sr[0];
+        for (int c4 = 1; c4 < vpr; ++c4) m = (m < sr[c4]) ? sr[c4] : m;
+        const int b = (int)(g / n_l);
+        const int i = (int)(g - (int64_t)b * n_l);
+        a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] =
+            sqrt_sigmoidf_(m) * sqrt_sigmoidf_(il);
+    }
+}
+
+static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
+                              float *rowmax, hipStream_t s)
+{
+    const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
+    if (t.C % ppl != 0 || t.C / ppl > kMaxVpr) return IA_E_ARG;
+    RowmaxNhwcArgs a;
+    a.t = t; a.p = p; a.rowmax = rowmax; a.batch = batch;
+    a.anchors_per_img = t.anchor_off[t.num_levels];
+    a.blk_off[0] = 0;
+    for (int rl = 0; rl < IA_MAX_LEVELS; ++rl) {
+        const int l = t.num_levels - 1 - rl;
+        int64_t n = 0;
+        if (l >= 0) {
+            if (((uintptr_t)p.cls[l] & 15u) != 0) return IA_E_ARG;      // 16-byte vector loads
+            n = ((int64_t)batch * (t.anchor_off[l + 1] - t.anchor_off[l]) + 63) / 64;
+        }
+        if (a.blk_off[rl] + n > 2147483647LL) return IA_E_ARG;
+        a.blk_off[rl + 1] = a.blk_off[rl] + (int32_t)n;
+    }
+    dim3 grid((unsigned)a.blk_off[t.num_levels]);
+    const int vpr = t.C / ppl;
+    if (dtype == IA_F32) {
+        if (vpr == 20) hipLaunchKernelGGL((k_rowmax_nhwc<float, 20>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_rowmax_nhwc<float, 0>), grid, dim3(64), 0, s, a);
+    } else {
+        if (vpr == 10) hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 10>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 0>), grid, dim3(64), 0, s, a);
+    }
+    return hip_status(hipGetLastError());
+}
+
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
                   hipStream_t s)
 {
     if (batch < 1 || !rowmax) return IA_E_ARG;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    if (t.layout == IA_LAYOUT_NHWC) return launch_rowmax_nhwc(t, p, batch, dtype, rowmax, s);
     const int tile = 64 * (dtype == IA_F32 ? Lane<float>::PPL : Lane<uint16_t>::PPL);
     RowmaxArgs a;
     a.t = t; a.p = p; a.rowmax = rowmax;
@@ -189,8 +291,14 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
     const int W = a.t.W[l], HW = a.t.H[l] * W;
     const int idx = a.cand_idx[(size_t)b * a.R + r];
     const int pos = idx / A, an = idx - pos * A;
-    const T *cls = static_cast<const T *>(a.p.cls[l]) + ((size_t)b * A + an) * C * HW + pos;
-    const T *iou = static_cast<const T *>(a.p.iou[l]) + ((size_t)b * A + an) * HW + pos;
+    // channel stride / element offsets of candidate (pos, an) in either memory order
+    const bool nhwc = a.t.layout == IA_LAYOUT_NHWC;
+    const size_t cs = nhwc ? (size_t)1 : (size_t)HW;
+    const size_t row = ((size_t)b * HW + pos) * A + an;                  // (B, HW, A) row id
+    const T *cls = static_cast<const T *>(a.p.cls[l]) +
+                   (nhwc ? row * C : ((size_t)b * A + an) * C * HW + pos);
+    const T *iou = static_cast<const T *>(a.p.iou[l]) +
+                   (nhwc ? row : ((size_t)b * A + an) * HW + pos);
     const float sq_iou = sqrt_sigmoidf_(load_f32<T>(iou));
     const int cpg = (C + kGroups - 1) / kGroups;
     const int c0 = grp * cpg;
@@ -199,7 +307,7 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
     float best = 0.0f;                           // scores are >= 0
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
-        float x = load_f32<T>(cls + (size_t)c * HW);
+        float x = load_f32<T>(cls + (size_t)c * cs);
         float sc = sqrt_sigmoidf_(x) * sq_iou;
         if (live) so[(size_t)c * a.Rs] = sc;
         best = (best < sc) ? sc : best;
@@ -212,7 +320,8 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
             for (int g2 = 1; g2 < kGroups; ++g2) best = (best < gmax[g2][lane]) ? gmax[g2][lane] : best;
             a.best_score[(size_t)b * a.R + r] = best;
         }
-        const T *reg = static_cast<const T *>(a.p.reg[l]) + ((size_t)b * A + an) * 4 * HW + pos;
+        const T *reg = static_cast<const T *>(a.p.reg[l]) +
+                       (nhwc ? row * 4 : ((size_t)b * A + an) * 4 * HW + pos);
         const int y = pos / W, x = pos - y * W;
         const float sx = (float)(x * a.t.stride[l]), sy = (float)(y * a.t.stride[l]);
         const float *ba = a.ba.v[l][an];
@@ -220,9 +329,9 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
         // delta2bbox, reference mmdet/core/bbox/transforms.py:50-76
         const float max_ratio = 4.135166556742356f;
         float dx = load_f32<T>(reg) * a.stds[0] + a.means[0];
-        float dy = load_f32<T>(reg + (size_t)HW) * a.stds[1] + a.means[1];
-        float dw = load_f32<T>(reg + (size_t)2 * HW) * a.stds[2] + a.means[2];
-        float dh = load_f32<T>(reg + (size_t)3 * HW) * a.stds[3] + a.means[3];
+        float dy = load_f32<T>(reg + cs) * a.stds[1] + a.means[1];
+        float dw = load_f32<T>(reg + 2 * cs) * a.stds[2] + a.means[2];
+        float dh = load_f32<T>(reg + 3 * cs) * a.stds[3] + a.means[3];
         dw = (dw < -max_ratio) ? -max_ratio : dw;  dw = (dw > max_ratio) ? max_ratio : dw;
         dh = (dh < -max_ratio) ? -max_ratio : dh;  dh = (dh > max_ratio) ? max_ratio : dh;
         float px = (ax1 + ax2) * 0.5f;

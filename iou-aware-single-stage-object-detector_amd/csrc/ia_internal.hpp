@@ -8,7 +8,7 @@ namespace ia {
 
 // per-level scalars used by kernels that do not need the base anchors
 struct LevelTable {
-    int32_t num_levels, A, C, nms_pre;
+    int32_t num_levels, A, C, nms_pre, layout;
     int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], stride[IA_MAX_LEVELS];
     int32_t anchor_off[IA_MAX_LEVELS + 1];   // prefix of N_l   (anchors per image)
     int32_t cand_off[IA_MAX_LEVELS + 1];     // prefix of k_l   (candidates per image)
@@ -24,6 +24,8 @@ inline int make_level_table(const ia_head_geom *g, LevelTable &t)
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS) return IA_E_ARG;
     if (g->num_classes < 1 || g->num_classes > 4096) return IA_E_ARG;
     if (g->nms_pre > IA_MAX_NMS_PRE) return IA_E_ARG;
+    if (g->layout != IA_LAYOUT_NCHW && g->layout != IA_LAYOUT_NHWC) return IA_E_ARG;
+    t.layout = g->layout;
     t.num_levels = g->num_levels; t.A = g->num_anchors; t.C = g->num_classes; t.nms_pre = g->nms_pre;
     t.anchor_off[0] = t.cand_off[0] = t.tile_off[0] = 0;
     for (int l = 0; l < IA_MAX_LEVELS; ++l) {

@@ -486,6 +486,7 @@ static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void
     if (!g || level < 0 || level >= g->num_levels || !bbox_pred || !iou_pred || !bt || !bw || B < 1)
         return IA_E_ARG;
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS) return IA_E_ARG;
+    if (g->layout != IA_LAYOUT_NCHW) return IA_E_ARG;            // training kernels: NCHW only
     if (!bwd && !loss_sum) return IA_E_ARG;
     IouBceArgs a;
     a.bbox_pred = bbox_pred; a.iou_pred = iou_pred; a.bbox_targets = bt; a.bbox_weights = bw;

@@ -50,12 +50,15 @@ __global__ void __launch_bounds__(kSelectThreads) k_select_part(SelectArgs a)
     const uint32_t cnt = (beg < n) ? ((n - beg < chunk) ? (n - beg) : chunk) : 0u;
     uint64_t *out = a.part_keys + ((size_t)b * a.parts_per_img + blockIdx.x) * a.kpad;
     const float *src = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
-    // storage order is anchor-major (a, p); the reference's anchor index is p*A + a
+    // NCHW heads store the row maxima anchor-major (a, p); the reference's anchor index is
+    // p*A + a, which is the storage order itself for channels-last heads
     const uint32_t HW = (uint32_t)(a.t.H[l] * a.t.W[l]), A = (uint32_t)a.t.A;
-    auto key = [src, HW, A, beg](uint32_t j) -> uint64_t {
+    const bool natural = a.t.layout == IA_LAYOUT_NHWC;
+    auto key = [src, HW, A, beg, natural](uint32_t j) -> uint64_t {
         const uint32_t i = beg + j;
         const uint32_t an = i / HW, p = i - an * HW;
-        return ((uint64_t)ordered_key(src[i]) << 32) | (uint64_t)(0xffffffffu - (p * A + an));
+        const uint32_t n = natural ? i : (p * A + an);
+        return ((uint64_t)ordered_key(src[i]) << 32) | (uint64_t)(0xffffffffu - n);
     };
     const uint32_t kk = (cnt < k) ? cnt : k;
     if (kk == cnt) {                            // the whole part survives: no selection needed

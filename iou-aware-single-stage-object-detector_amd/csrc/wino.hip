@@ -1,0 +1,285 @@
+// Winograd F(4x4, 3x3) transforms for the 3x3 / stride-1 / pad-1 convolutions of the head
+// (reference iou_aware_retina_head.py:171-219: 4+4 tower convs 256->256, retina_cls 256->720,
+// retina_reg 256->36, retina_iou 256->9, weights shared by the five pyramid levels) and of the
+// FPN outputs.  Those convolutions are 63 % of the network's multiply-adds at 800x1344; as direct
+// / implicit-GEMM fp32 convolutions they run at ~110-125 TFLOP/s of the 157 TFLOP/s MFMA peak, so
+// the only large lever left is the number of multiplications: F(4x4,3x3) needs 36 per 16 outputs
+// instead of 144.
+//
+// Split of work:
+//   k_wino_in   (this file)   d (6x6 input patch per tile, zero padded) -> V = B^T d B, scattered
+//                             as 36 matrices V[k] of (tiles x Cin); ALL pyramid levels of the
+//                             batch form one tile list, so the shared-weight head needs ONE
+//                             batched GEMM per layer instead of five small ones;
+//   batched GEMM              M[k] = V[k] (tiles x Cin) . U[k] (Cin x Cout), 36 (x groups) plain
+//                             fp32 GEMMs -> rocBLAS / hipBLASLt through torch.bmm (library GEMM);
+//   k_wino_out  (this file)   Y = A^T M A (4x4 outputs per tile) + bias (+ ReLU), written straight
+//                             into the channels-last activation / head-output tensors.
+// Activations are channels-last fp32: a wavefront handles one tile x 256 channels, 16 bytes per
+// lane, so every load / store instruction moves one contiguous 1 KiB pixel row.  Both kernels
+// are HBM-bound streams (36 x 16 B in, 36 x 16 B out per lane; 36 in, 16 out).
+// Transform matrices: Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks"
+// (interpolation points 0, +-1, +-2, inf); weights are transformed once on the host side
+// (U = G g G^T in fp64, iouaware/winograd.py).
+#include <string.h>
+#include "ia_internal.hpp"
+
+namespace ia {
+
+struct WinoLevels {
+    int32_t L, B;
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], tx[IA_MAX_LEVELS], tpi[IA_MAX_LEVELS];
+    int32_t tile_off[IA_MAX_LEVELS + 1];      // prefix of B * tiles_per_image
+};
+
+static int make_wino_levels(const ia_wino_geom *g, WinoLevels &w)
+{
+    if (!g || g->num_levels < 1 || g->num_levels > IA_MAX_LEVELS || g->batch < 1) return IA_E_ARG;
+    w.L = g->num_levels; w.B = g->batch;
+    w.tile_off[0] = 0;
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        const bool on = l < g->num_levels;
+        if (on && (g->H[l] < 1 || g->W[l] < 1)) return IA_E_ARG;
+        w.H[l] = on ? g->H[l] : 0; w.W[l] = on ? g->W[l] : 0;
+        w.tx[l] = (w.W[l] + 3) / 4;
+        w.tpi[l] = ((w.H[l] + 3) / 4) * w.tx[l];
+        const int64_t n = (int64_t)w.tile_off[l] + (int64_t)g->batch * w.tpi[l];
+        if (n > 2147483647LL) return IA_E_ARG;
+        w.tile_off[l + 1] = (int32_t)n;
+    }
+    return 0;
+}
+
+struct TileRef { int l, b, y0, x0; };
+
+__device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t)
+{
+    TileRef r;
+    int l = 0;
+    while (t >= w.tile_off[l + 1]) ++l;
+    const int q = t - w.tile_off[l];
+    r.l = l; r.b = q / w.tpi[l];
+    const int i = q - r.b * w.tpi[l];
+    const int ty = i / w.tx[l];
+    r.y0 = 4 * ty; r.x0 = 4 * (i - ty * w.tx[l]);
+    return r;
+}
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(const float4 &a, const float4 &b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(const float4 &a, const float4 &b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, const float4 &a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// one line of B^T d (the same 6-point transform is applied to rows, then to columns)
+__device__ __forceinline__ void bt6(const float4 (&d)[6], float4 (&o)[6])
+{
+    o[0] = (4.0f * d[0] - 5.0f * d[2]) + d[4];
+    o[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+    o[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
+    o[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+    o[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+    o[5] = (4.0f * d[1] - 5.0f * d[3]) + d[5];
+}
+
+// one line of A^T m
+__device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&o)[4])
+{
+    const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    o[0] = (m[0] + s12) + s34;
+    o[1] = d12 + 2.0f * d34;
+    o[2] = s12 + 4.0f * s34;
+    o[3] = (d12 + 8.0f * d34) + m[5];
+}
+
+struct WinoInArgs {
+    WinoLevels lv;
+    const float *x[IA_MAX_LEVELS];        // per level (B, H, W, Ctot) channels-last
+    float *V;                             // (groups * 36, T, Cg)
+    int32_t Ctot, Cg, T;
+};
+
+__global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
+{
+    const int t = blockIdx.x;
+    const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
+    if (c >= a.Ctot) return;
+    const TileRef r = locate_tile(a.lv, t);
+    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
+    const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
+    float4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int y = r.y0 - 1 + i;
+        const bool yin = (y >= 0) && (y < H);
+        const int yc = yin ? y : 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = r.x0 - 1 + j;
+            const bool in = yin && (xx >= 0) && (xx < W);
+            const int xc = (xx >= 0 && xx < W) ? xx : 0;
+            // the load is unconditional (clamped address); padding is selected afterwards
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
+            d[i][j] = in ? v : f4(0.0f);
+        }
+    }
+    float4 tmp[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                       // columns: tmp = B^T d
+        float4 col[6], o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+        bt6(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    }
+    const int g = c / a.Cg, cc = c - g * a.Cg;
+    float *v = a.V + ((size_t)g * 36 * a.T + t) * a.Cg + cc;
+    const size_t kstride = (size_t)a.T * a.Cg;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                       // rows: V = tmp B
+        float4 o[6];
+        bt6(tmp[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            *reinterpret_cast<float4 *>(v + (size_t)(i * 6 + j) * kstride) = o[j];
+    }
+}
+
+constexpr int kMaxSeg = 4;
+
+struct WinoSeg {                          // output channels [c0, c0 + n) -> dst tensors with Cdst channels
+    int32_t c0, n, Cdst, coff;
+    float *dst[IA_MAX_LEVELS];
+};
+
+struct WinoOutArgs {
+    WinoLevels lv;
+    const float *M;                       // (groups * 36, T, Cg)
+    const float *bias;                    // (groups * Cg) or NULL
+    WinoSeg seg[kMaxSeg];
+    int32_t nseg, Ctot, Cg, T, relu;
+};
+
+__global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
+{
+    const int t = blockIdx.x;
+    const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
+    if (c >= a.Ctot) return;
+    const TileRef r = locate_tile(a.lv, t);
+    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
+    const int g = c / a.Cg, cc = c - g * a.Cg;
+    const float *m = a.M + ((size_t)g * 36 * a.T + t) * a.Cg + cc;
+    const size_t kstride = (size_t)a.T * a.Cg;
+    float4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                       // columns: s = A^T m
+        float4 col[6], o[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4 *>(m + (size_t)(i * 6 + j) * kstride);
+        at6(col, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+    }
+    float4 bz = f4(0.0f);
+    if (a.bias) bz = *reinterpret_cast<const float4 *>(a.bias + c);
+    // destination of this lane's four channels
+    int si = 0;
+    while (si + 1 < a.nseg && c >= a.seg[si].c0 + a.seg[si].n) ++si;
+    const WinoSeg &sg = a.seg[si];
+    const bool whole = (c >= sg.c0) && (c + 4 <= sg.c0 + sg.n) && (((sg.coff + c - sg.c0) & 3) == 0) &&
+                       ((sg.Cdst & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                       // rows: Y = s A
+        float4 o[4];
+        at6(s[i], o);
+        const int y = r.y0 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = r.x0 + j;
+            if (y >= H || xx >= W) continue;
+            float4 v = o[j] + bz;
+            if (a.relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f,
+                                        v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            const size_t pix = ((size_t)r.b * H + y) * W + xx;
+            if (whole) {
+                *reinterpret_cast<float4 *>(sg.dst[r.l] + pix * sg.Cdst + sg.coff + (c - sg.c0)) = v;
+            } else {                                    // a lane that straddles segments / padding
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = c + q;
+                    for (int k = 0; k < a.nseg; ++k) {
+                        const WinoSeg &z = a.seg[k];
+                        if (ch >= z.c0 && ch < z.c0 + z.n)
+                            z.dst[r.l][pix * z.Cdst + z.coff + (ch - z.c0)] = e[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ia
+
+extern "C" {
+
+int ia_wino_tiles(const ia_wino_geom *g, int32_t *tiles)
+{
+    ia::WinoLevels w;
+    int rc = ia::make_wino_levels(g, w);
+    if (rc) return rc;
+    if (tiles) *tiles = w.tile_off[w.L];
+    return 0;
+}
+
+int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int channels, int groups,
+                            float *V, void *stream)
+{
+    ia::WinoInArgs a;
+    int rc = ia::make_wino_levels(g, a.lv);
+    if (rc) return rc;
+    if (!x || !V || channels < 4 || (channels & 3) || groups < 1 || channels % groups) return IA_E_ARG;
+    a.Ctot = channels; a.Cg = channels / groups; a.T = a.lv.tile_off[a.lv.L];
+    if (a.Cg & 3) return IA_E_ARG;
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        a.x[l] = (l < a.lv.L) ? x[l] : nullptr;
+        if (l < a.lv.L && (!x[l] || ((uintptr_t)x[l] & 15u))) return IA_E_ARG;
+    }
+    a.V = V;
+    dim3 grid((unsigned)a.T, (unsigned)((channels / 4 + 63) / 64));
+    hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
+
+int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels, int groups,
+                             const float *bias, int relu, int nseg, const ia_wino_seg *segs,
+                             void *stream)
+{
+    ia::WinoOutArgs a;
+    int rc = ia::make_wino_levels(g, a.lv);
+    if (rc) return rc;
+    if (!M || channels < 4 || (channels & 3) || groups < 1 || channels % groups || !segs ||
+        nseg < 1 || nseg > ia::kMaxSeg)
+        return IA_E_ARG;
+    a.M = M; a.bias = bias; a.Ctot = channels; a.Cg = channels / groups;
+    if (a.Cg & 3) return IA_E_ARG;
+    a.T = a.lv.tile_off[a.lv.L]; a.relu = relu ? 1 : 0; a.nseg = nseg;
+    memset(a.seg, 0, sizeof(a.seg));
+    for (int k = 0; k < nseg; ++k) {
+        const ia_wino_seg &s = segs[k];
+        if (s.c0 < 0 || s.n < 1 || s.c0 + s.n > channels || s.dst_channels < s.n + s.dst_offset ||
+            s.dst_offset < 0)
+            return IA_E_ARG;
+        if (k > 0 && s.c0 < segs[k - 1].c0 + segs[k - 1].n) return IA_E_ARG;       // ascending
+        a.seg[k].c0 = s.c0; a.seg[k].n = s.n; a.seg[k].Cdst = s.dst_channels; a.seg[k].coff = s.dst_offset;
+        for (int l = 0; l < a.lv.L; ++l) {
+            if (!s.dst[l]) return IA_E_ARG;
+            a.seg[k].dst[l] = s.dst[l];
+        }
+    }
+    dim3 grid((unsigned)a.T, (unsigned)((channels / 4 + 63) / 64));
+    hipLaunchKernelGGL(ia::k_wino_out, grid, dim3(64), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
+
+}  // extern "C"

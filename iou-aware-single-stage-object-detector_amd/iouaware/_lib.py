@@ -13,6 +13,7 @@ IA_MAX_NMS_PRE = 4096
 IA_MAX_CANDIDATES = 8192
 IA_MAX_PER_IMG = 1024
 IA_F32, IA_BF16 = 0, 1
+IA_LAYOUT_NCHW, IA_LAYOUT_NHWC = 0, 1
 IA_LOSS_SLOTS = 64
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
@@ -25,7 +26,7 @@ class HeadGeom(C.Structure):
                 ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS),
                 ('stride', C.c_int32 * IA_MAX_LEVELS),
                 ('base_anchors', ((C.c_float * 4) * IA_MAX_ANCHORS) * IA_MAX_LEVELS),
-                ('means', C.c_float * 4), ('stds', C.c_float * 4)]
+                ('means', C.c_float * 4), ('stds', C.c_float * 4), ('layout', C.c_int32)]
 
 
 class LevelPtrs(C.Structure):
@@ -36,6 +37,16 @@ class LevelPtrs(C.Structure):
 class ImageDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('src_h', C.c_int32), ('src_w', C.c_int32),
                 ('dst_h', C.c_int32), ('dst_w', C.c_int32), ('flip', C.c_int32)]
+
+
+class WinoGeom(C.Structure):
+    _fields_ = [('num_levels', C.c_int32), ('batch', C.c_int32),
+                ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS)]
+
+
+class WinoSeg(C.Structure):
+    _fields_ = [('c0', C.c_int32), ('n', C.c_int32), ('dst_channels', C.c_int32),
+                ('dst_offset', C.c_int32), ('dst', C.c_void_p * IA_MAX_LEVELS)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -64,6 +75,10 @@ SIGNATURES = {
     'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'ia_image_transform': (_i, [C.POINTER(ImageDesc), _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                 _i, _i, _i, _i, _vp, _vp]),
+    'ia_wino_tiles': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_int32)]),
+    'ia_wino_input_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _i, _vp, _vp]),
+    'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
+                                      C.POINTER(WinoSeg), _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

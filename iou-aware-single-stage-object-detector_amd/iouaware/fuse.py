@@ -104,10 +104,27 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     return ops.channel_affine_act_(_conv_nobias(self.conv, x), None, f['bias'], relu=relu)
 
 
-def fuse_inference(model):
-    """Patch `model` in place (see module docstring).  Returns the number of fused modules."""
+def _head_forward(self, feats):
+    w = self._ia_wino
+    if (not self.training) and w.usable(feats):
+        return w(list(feats))
+    return type(self).forward(self, feats)
+
+
+def fuse_inference(model, winograd=False):
+    """Patch `model` in place (see module docstring).  Returns the number of fused modules.
+
+    winograd=True additionally routes the head's 3x3 convolutions through the Winograd
+    F(4x4,3x3) path (iouaware/winograd.py) whenever its inputs are channels-last fp32 CUDA
+    tensors: all pyramid levels in one batched GEMM per layer."""
     n = 0
     for m in model.modules():
+        if winograd and type(m).__name__ == 'IoUawareRetinaHead':
+            from .winograd import WinogradHead
+            m._ia_wino = WinogradHead(m)
+            m.forward = types.MethodType(_head_forward, m)
+            n += 1
+            continue
         if isinstance(m, Bottleneck):
             f = {}
             f['s1'], f['b1'] = _fold_bn(m.norm1)
@@ -148,7 +165,8 @@ def fuse_inference(model):
 
 def unfuse_inference(model):
     for m in model.modules():
-        if hasattr(m, '_ia_fused'):
-            del m._ia_fused
-            if 'forward' in m.__dict__:
-                del m.__dict__['forward']
+        for attr in ('_ia_fused', '_ia_wino'):
+            if hasattr(m, attr):
+                delattr(m, attr)
+                if 'forward' in m.__dict__:
+                    del m.__dict__['forward']

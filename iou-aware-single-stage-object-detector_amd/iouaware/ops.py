@@ -68,9 +68,24 @@ class HeadGeometry(object):
         self.N, self.R, self.Rs = n.value, r.value, rs.value
         self.level_anchors = [h * w * A for (h, w) in self.featmap_sizes]
         self.level_cands = [min(nms_pre, n_) if nms_pre > 0 else n_ for n_ in self.level_anchors]
+        self.layout = _lib.IA_LAYOUT_NCHW
+        self._twin = None
 
     def ref(self):
         return C.byref(self.struct)
+
+    def with_layout(self, layout):
+        """the same geometry for head outputs stored in the other memory order"""
+        if layout == self.layout:
+            return self
+        if self._twin is None:
+            import copy
+            t = copy.copy(self)
+            t.struct = HeadGeom.from_buffer_copy(self.struct)
+            t.struct.layout = layout
+            t.layout, t._twin = layout, self
+            self._twin = t
+        return self._twin
 
 
 def to_nchw(t):
@@ -88,13 +103,28 @@ def to_nchw(t):
     return t.contiguous()
 
 
+def _nhwc_ok(geom, tensors):
+    """channels-last head outputs are consumed in place (no transposes) when every tensor is
+    channels-last contiguous and a class row is a whole number (<= 32) of 16-byte vectors"""
+    row = geom.C * tensors[0].element_size()
+    if row % 16 != 0 or row > 512:
+        return False
+    if all(t.is_contiguous() for t in tensors):
+        return False
+    return all(t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+               for t in tensors)
+
+
 def level_ptrs(geom, cls, reg, iou):
-    """Validate the per-level head outputs and pack their device pointers."""
+    """Validate the per-level head outputs and pack their device pointers.
+    -> (ptrs, batch, dtype code, geometry for the memory order the tensors are in)"""
     if not (len(cls) == len(reg) == len(iou) == geom.L):
         raise AssertionError('expected %d levels' % geom.L)
     p = LevelPtrs()
     B = cls[0].shape[0]
     dt = _dtype_code(cls[0])
+    nhwc = _nhwc_ok(geom, list(cls) + list(reg) + list(iou))
+    geom = geom.with_layout(_lib.IA_LAYOUT_NHWC if nhwc else _lib.IA_LAYOUT_NCHW)
     for l in range(geom.L):
         h, w = geom.featmap_sizes[l]
         for name, t, ch in (('cls_score', cls[l], geom.A * geom.C), ('bbox_pred', reg[l], geom.A * 4),
@@ -105,11 +135,12 @@ def level_ptrs(geom, cls, reg, iou):
                                      % (name, l, tuple(t.shape), (B, ch, h, w)))
             if _dtype_code(t) != dt:
                 raise TypeError('mixed dtypes in head outputs')
-        cls[l] = to_nchw(cls[l])
-        reg[l] = to_nchw(reg[l])
-        iou[l] = to_nchw(iou[l])
+        if not nhwc:
+            cls[l] = to_nchw(cls[l])
+            reg[l] = to_nchw(reg[l])
+            iou[l] = to_nchw(iou[l])
         p.cls[l], p.reg[l], p.iou[l] = cls[l].data_ptr(), reg[l].data_ptr(), iou[l].data_ptr()
-    return p, B, dt
+    return p, B, dt, geom
 
 
 _ws_cache = {}
@@ -148,6 +179,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     """
     cls, reg, iou = list(cls), list(reg), list(iou)
     if soft is not None:
+        geom = geometry_for(geom, cls, reg, iou)
         cand = select_topk(geom, decode_fuse_rowmax(geom, cls, reg, iou))
         boxes, scores_t, _ = gather_decode(geom, cls, reg, iou, cand, img_shapes, scale_factors,
                                            rescale)
@@ -156,7 +188,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
             return out[:4]
         return out[:4] + (dict(cand_idx=cand, boxes=boxes, scores_t=scores_t, keep_count=out[4],
                                keep_rows=out[5]),)
-    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    p, B, dt, geom = level_ptrs(geom, cls, reg, iou)
     dev = cls[0].device
     L = _lib.lib()
     nbytes = L.ia_get_bboxes_workspace_bytes(geom.ref(), B)
@@ -190,9 +222,16 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
 
 
 # ----------------------------------------------------------------- stage wrappers
+def geometry_for(geom, cls, reg, iou):
+    """the geometry object matching the memory order (NCHW / channels-last) of these head
+    outputs: pass it to the stage wrappers so that select_topk reads the row maxima in the
+    order decode_fuse_rowmax wrote them"""
+    return level_ptrs(geom, list(cls), list(reg), list(iou))[3]
+
+
 def decode_fuse_rowmax(geom, cls, reg, iou):
     cls, reg, iou = list(cls), list(reg), list(iou)
-    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    p, B, dt, geom = level_ptrs(geom, cls, reg, iou)
     out = torch.empty((B, geom.N), dtype=torch.float32, device=cls[0].device)
     _lib.check(_lib.lib().ia_decode_fuse_rowmax(geom.ref(), C.byref(p), B, dt, _ptr(out),
                                                 _stream()), 'ia_decode_fuse_rowmax')
@@ -213,7 +252,7 @@ def select_topk(geom, rowmax):
 
 def gather_decode(geom, cls, reg, iou, cand_idx, img_shapes, scale_factors, rescale):
     cls, reg, iou = list(cls), list(reg), list(iou)
-    p, B, dt = level_ptrs(geom, cls, reg, iou)
+    p, B, dt, geom = level_ptrs(geom, cls, reg, iou)
     dev = cls[0].device
     hw, sf = _meta_tensors(img_shapes, scale_factors, dev)
     boxes = torch.empty((B, geom.R, 4), dtype=torch.float32, device=dev)

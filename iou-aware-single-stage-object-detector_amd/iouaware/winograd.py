@@ -1,0 +1,214 @@
+"""Winograd F(4x4,3x3) inference path for the 3x3 / stride-1 convolutions of the IoU-aware
+RetinaNet head (reference iou_aware_retina_head.py:171-219: cls / reg towers, retina_cls,
+retina_reg, retina_iou) and of the FPN output convolutions (fpn.py:124-127).
+
+    activations (channels-last, all five levels)  --k_wino_in-->   V  (36 matrices tiles x Cin)
+    V . U   (36 [x2 towers] plain fp32 GEMMs, torch.bmm -> rocBLAS / hipBLASLt)  -->  M
+    M  --k_wino_out (+bias, +ReLU)-->  next activations / the head outputs, channels-last
+
+The head's weights are shared by the pyramid levels, so every layer is ONE batched GEMM over the
+tiles of all levels; the two towers run side by side (first layer: one GEMM with 512 output
+columns on the shared input, later layers: 72 matrices).  36 multiplications per 4x4 output tile
+instead of 144: these convolutions are 63 % of the network's multiply-adds.
+
+Numerics: fp32 throughout; the Winograd transforms reassociate the sums, outputs agree with a
+direct convolution to ~1e-5 of the activation scale (tests/test_gpu_winograd.py).  The weights are
+transformed once (fp64 -> fp32) when the runner is built: build it AFTER loading a checkpoint.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream
+
+_G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+               [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+
+
+def transform_weight(w):
+    """(Cout, Cin, 3, 3) conv weight -> U (36, Cin, Cout) fp32, U[6i+j] = (G g G^T)[i, j]."""
+    if w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
+        raise ValueError('Winograd F(4,3) needs a 3x3 kernel, got %s' % (tuple(w.shape),))
+    g = w.detach().to(torch.float64)
+    G = torch.from_numpy(_G).to(g.device)
+    u = torch.einsum('ik,ockl,jl->ijco', G, g, G)           # (6, 6, Cin, Cout)
+    return u.reshape(36, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
+
+
+def _wino_geom(sizes, batch):
+    g = _lib.WinoGeom()
+    g.num_levels, g.batch = len(sizes), int(batch)
+    for l, (h, w) in enumerate(sizes):
+        g.H[l], g.W[l] = int(h), int(w)
+    tiles = C.c_int32()
+    _lib.check(_lib.lib().ia_wino_tiles(C.byref(g), C.byref(tiles)), 'ia_wino_tiles')
+    return g, tiles.value
+
+
+def _usable(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _Plan(object):
+    """buffers of one (batch, feature-map sizes) configuration"""
+
+    def __init__(self, sizes, batch, device):
+        self.sizes, self.batch = list(sizes), batch
+        self.geom, self.T = _wino_geom(sizes, batch)
+        self.device = device
+        self._bufs = {}
+
+    def buf(self, name, shape):
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._bufs[name] = b
+        return b
+
+    def acts(self, name, channels):
+        """per-level channels-last activation tensors (B, C, H, W)"""
+        key = ('acts', name, channels)
+        a = self._bufs.get(key)
+        if a is None:
+            a = [torch.empty((self.batch, channels, h, w), dtype=torch.float32, device=self.device,
+                             memory_format=torch.channels_last) for (h, w) in self.sizes]
+            self._bufs[key] = a
+        return a
+
+
+def input_transform(plan, xs, groups, out):
+    ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    _lib.check(_lib.lib().ia_wino_input_transform(C.byref(plan.geom), ptrs, int(xs[0].shape[1]),
+                                                  int(groups), _ptr(out), _stream()),
+               'ia_wino_input_transform')
+    return out
+
+
+def output_transform(plan, m, channels, groups, bias, relu, segments):
+    """segments: list of (c0, n, dst_tensors, dst_offset)"""
+    segs = (_lib.WinoSeg * len(segments))()
+    for k, (c0, n, dst, off) in enumerate(segments):
+        segs[k].c0, segs[k].n = int(c0), int(n)
+        segs[k].dst_channels, segs[k].dst_offset = int(dst[0].shape[1]), int(off)
+        for l, t in enumerate(dst):
+            segs[k].dst[l] = t.data_ptr()
+    _lib.check(_lib.lib().ia_wino_output_transform(C.byref(plan.geom), _ptr(m), int(channels),
+                                                   int(groups), _ptr(bias), int(bool(relu)),
+                                                   len(segments), segs, _stream()),
+               'ia_wino_output_transform')
+
+
+class WinogradConv3x3(object):
+    """one 3x3 / stride-1 / pad-1 convolution (+bias, +ReLU) over a list of channels-last level
+    tensors that do NOT share the weight with other layers' inputs (FPN output convs: one
+    instance per level)."""
+
+    def __init__(self, weight, bias, relu=False):
+        self.u = transform_weight(weight)
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        self.relu = relu
+        self.cin, self.cout = self.u.shape[1], self.u.shape[2]
+        if self.cout % 4:
+            raise ValueError('output channels must be a multiple of 4')
+        self._plans = {}
+
+    def __call__(self, x):
+        key = (x.shape[0], tuple(x.shape[-2:]), x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _Plan([tuple(x.shape[-2:])], x.shape[0], x.device)
+        v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)))
+        m = torch.bmm(v, self.u, out=plan.buf('m', (36, plan.T, self.cout)))
+        y = torch.empty((x.shape[0], self.cout) + tuple(x.shape[-2:]), dtype=torch.float32,
+                        device=x.device, memory_format=torch.channels_last)
+        output_transform(plan, m, self.cout, 1, self.bias, self.relu, [(0, self.cout, [y], 0)])
+        return y
+
+
+class WinogradHead(object):
+    """the conv towers and output convolutions of an IoUawareRetinaHead, all levels at once."""
+
+    def __init__(self, head):
+        convs_c, convs_r = list(head.cls_convs), list(head.reg_convs)
+        if any(m.with_norm or not m.with_activatation for m in convs_c + convs_r):
+            raise NotImplementedError('towers with norm layers / without ReLU')
+        self.n_layers = len(convs_c)
+        F = head.feat_channels
+        if head.in_channels % 4 or F % 4:
+            raise ValueError('channel counts must be multiples of 4')
+        self.F, self.cin = F, head.in_channels
+
+        def wb(m):
+            conv = m.conv
+            b = conv.bias if conv.bias is not None else torch.zeros(conv.out_channels,
+                                                                     device=conv.weight.device)
+            return transform_weight(conv.weight), b.detach().float()
+
+        # layer 0: both towers read the FPN feature -> one GEMM with 2F output columns
+        (uc, bc), (ur, br) = wb(convs_c[0]), wb(convs_r[0])
+        self.u0 = torch.cat([uc, ur], dim=2).contiguous()               # (36, Cin, 2F)
+        self.b0 = torch.cat([bc, br]).contiguous()
+        # layers 1..: two groups side by side -> 72 matrices
+        self.u, self.b = [], []
+        for i in range(1, self.n_layers):
+            (uc, bc), (ur, br) = wb(convs_c[i]), wb(convs_r[i])
+            self.u.append(torch.cat([uc, ur], dim=0).contiguous())       # (72, F, F)
+            self.b.append(torch.cat([bc, br]).contiguous())
+        # outputs: retina_cls on the cls tower; retina_reg | retina_iou on the reg tower
+        self.c_cls = head.retina_cls.out_channels
+        self.c_reg, self.c_iou = head.retina_reg.out_channels, head.retina_iou.out_channels
+        if self.c_cls % 4:
+            raise ValueError('A*C must be a multiple of 4')
+        self.u_cls = transform_weight(head.retina_cls.weight)
+        self.b_cls = head.retina_cls.bias.detach().float().contiguous()
+        n_ri = self.c_reg + self.c_iou
+        self.n_ri_pad = (n_ri + 15) // 16 * 16
+        u_ri = torch.zeros((36, F, self.n_ri_pad), dtype=torch.float32, device=self.u_cls.device)
+        u_ri[:, :, :self.c_reg] = transform_weight(head.retina_reg.weight)
+        u_ri[:, :, self.c_reg:n_ri] = transform_weight(head.retina_iou.weight)
+        self.u_ri = u_ri.contiguous()
+        b_ri = torch.zeros(self.n_ri_pad, dtype=torch.float32, device=self.u_cls.device)
+        b_ri[:self.c_reg] = head.retina_reg.bias.detach().float()
+        b_ri[self.c_reg:n_ri] = head.retina_iou.bias.detach().float()
+        self.b_ri = b_ri.contiguous()
+        self._plans = {}
+
+    def usable(self, feats):
+        return all(_usable(x) and x.shape[1] == self.cin for x in feats) \
+            and not torch.is_grad_enabled()
+
+    def __call__(self, feats):
+        """feats: per-level (B, Cin, H, W) channels-last fp32 -> (cls[L], reg[L], iou[L])"""
+        B = feats[0].shape[0]
+        sizes = [tuple(x.shape[-2:]) for x in feats]
+        key = (B, tuple(sizes), feats[0].device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _Plan(sizes, B, feats[0].device)
+        T, F = plan.T, self.F
+        # layer 0
+        v = input_transform(plan, feats, 1, plan.buf('v0', (36, T, self.cin)))
+        m = torch.bmm(v, self.u0, out=plan.buf('m0', (36, T, 2 * F)))
+        acts = plan.acts('a', 2 * F)
+        output_transform(plan, m, 2 * F, 1, self.b0, True, [(0, 2 * F, acts, 0)])
+        # layers 1..n-1: groups = 2 (cls tower = channels [0,F), reg tower = [F,2F))
+        for u, b in zip(self.u, self.b):
+            v = input_transform(plan, acts, 2, plan.buf('v', (72, T, F)))
+            m = torch.bmm(v, u, out=plan.buf('m', (72, T, F)))
+            nxt = plan.acts('b' if acts is plan.acts('a', 2 * F) else 'a', 2 * F)
+            output_transform(plan, m, 2 * F, 2, b, True, [(0, 2 * F, nxt, 0)])
+            acts = nxt
+        # outputs
+        v = input_transform(plan, acts, 2, plan.buf('v', (72, T, F)))
+        m_cls = torch.bmm(v[:36], self.u_cls, out=plan.buf('mc', (36, T, self.c_cls)))
+        m_ri = torch.bmm(v[36:], self.u_ri, out=plan.buf('mr', (36, T, self.n_ri_pad)))
+        new = lambda c: [torch.empty((B, c, h, w), dtype=torch.float32, device=feats[0].device,  # noqa: E731
+                                     memory_format=torch.channels_last) for (h, w) in sizes]
+        cls, reg, iou = new(self.c_cls), new(self.c_reg), new(self.c_iou)
+        output_transform(plan, m_cls, self.c_cls, 1, self.b_cls, False, [(0, self.c_cls, cls, 0)])
+        output_transform(plan, m_ri, self.n_ri_pad, 1, self.b_ri, False,
+                         [(0, self.c_reg, reg, 0), (self.c_reg, self.c_iou, iou, 0)])
+        return cls, reg, iou

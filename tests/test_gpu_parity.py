@@ -60,9 +60,22 @@ def oracle_image(oracle_lib, cls, reg, iou, b, base, img_hw, sf, rescale, nms_pr
 def check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr,
                          iou_thr, max_per_img, dtype=torch.float32, means=(0, 0, 0, 0),
                          stds=(1, 1, 1, 1)):
-    """runs the whole HIP path with debug views and compares every stage bit for bit"""
+    """both memory orders of the head outputs: NCHW (k_rowmax) and channels-last, consumed in
+    place (k_rowmax_nhwc) -- every stage bit for bit against the oracle"""
+    for channels_last in (True, False):
+        out = _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr,
+                            iou_thr, max_per_img, dtype, means, stds, channels_last)
+    return out
+
+
+def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr, iou_thr,
+                  max_per_img, dtype, means, stds, channels_last):
     B = cls[0].shape[0]
     dc, dr, di = G.to_dev(cls, dtype), G.to_dev(reg, dtype), G.to_dev(iou, dtype)
+    if channels_last:
+        dc, dr, di = [[t.contiguous(memory_format=torch.channels_last) for t in x]
+                      for x in (dc, dr, di)]
+        assert ops.geometry_for(geom, dc, dr, di).layout == 1
     shapes = [m['img_shape'] for m in metas]
     sfs = [m['scale_factor'] for m in metas]
     dets, labels, rows, num, dbg = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale,
@@ -75,11 +88,14 @@ def check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, resc
     for b in range(B):
         o = oracle_image(oracle_lib, cls, reg, iou, b, base, shapes[b][:2], sfs[b], rescale,
                          geom.struct.nms_pre, score_thr, iou_thr, max_per_img, means, stds)
-        # device layout: per level an (A, HW) block; oracle: reference order p*A + a
+        # device layout for NCHW heads: per level an (A, HW) block; channels-last heads and the
+        # oracle: reference order p*A + a
         off = 0
         for (h, w) in geom.featmap_sizes:
             n_l = h * w * geom.A
-            dev = dbg['rowmax'][b][off:off + n_l].reshape(geom.A, h * w).T.reshape(-1)
+            dev = dbg['rowmax'][b][off:off + n_l]
+            if not channels_last:
+                dev = dev.reshape(geom.A, h * w).T.reshape(-1)
             assert G.same_bits(dev, o['rowmax'][off:off + n_l]), 'rowmax img %d' % b
             off += n_l
         assert np.array_equal(dbg['cand_idx'][b], o['topk_inds']), 'topk img %d' % b
@@ -184,6 +200,12 @@ def test_stage_entry_points(ops, oracle_lib):
     geom, base = G.geometry(ph, pw, 300)
     dc, dr, di = G.to_dev(cls), G.to_dev(reg), G.to_dev(iou)
     shapes, sfs = [(120, 157, 3)] * 2, [1.0, 1.3]
+    _stage_chain(ops, geom, dc, dr, di, shapes, sfs)
+    dc, dr, di = [[t.contiguous(memory_format=torch.channels_last) for t in x] for x in (dc, dr, di)]
+    _stage_chain(ops, ops.geometry_for(geom, dc, dr, di), dc, dr, di, shapes, sfs)
+
+
+def _stage_chain(ops, geom, dc, dr, di, shapes, sfs):
     rm = ops.decode_fuse_rowmax(geom, dc, dr, di)
     idx = ops.select_topk(geom, rm)
     boxes, scores_t, best = ops.gather_decode(geom, dc, dr, di, idx, shapes, sfs, True)
@@ -289,3 +311,33 @@ def test_full_size_batch8_properties(ops, oracle_lib):
                     ai = (bb[i, 2] - bb[i, 0] + 1) * (bb[i, 3] - bb[i, 1] + 1)
                     aj = (bb[j, 2] - bb[j, 0] + 1) * (bb[j, 3] - bb[j, 1] + 1)
                     assert inter / (ai + aj - inter) < 0.5
+
+
+@pytest.mark.parametrize('Cn,dtype', [(12, torch.float32), (4, torch.float32), (128, torch.float32),
+                                      (8, torch.bfloat16), (40, torch.bfloat16)])
+def test_channels_last_other_class_counts(ops, oracle_lib, Cn, dtype):
+    """the run-time vectors-per-row path of k_rowmax_nhwc (C*sizeof != 320 / 160 bytes)"""
+    ph, pw, B = 96, 128, 2
+    sizes = synth.level_shapes(ph, pw)
+    base = oracle_lib.head_base_anchors(synth.STRIDES)
+    geom = ops.HeadGeometry(sizes, synth.STRIDES, base, Cn, nms_pre=200)
+    rs = np.random.RandomState(Cn)
+    cls = [(rs.standard_normal((B, 9 * Cn, h, w)) * 2 - 3).astype(np.float32) for (h, w) in sizes]
+    reg = [(rs.standard_normal((B, 36, h, w)) * 0.5).astype(np.float32) for (h, w) in sizes]
+    iou = [(rs.standard_normal((B, 9, h, w)) * 1.5).astype(np.float32) for (h, w) in sizes]
+    if dtype == torch.bfloat16:
+        cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
+    dev = [[t.contiguous(memory_format=torch.channels_last) for t in G.to_dev(x, dtype)]
+           for x in (cls, reg, iou)]
+    assert ops.geometry_for(geom, *dev).layout == 1
+    dets, labels, rows, num = ops.get_bboxes(geom, *dev, [(90, 125, 3)] * B, [1.0] * B, True, 0.05,
+                                             0.5, 100)
+    for b in range(B):
+        o = oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
+                                         [x[b] for x in iou], synth.STRIDES, base, (90, 125), 1.0,
+                                         True, 200, 0.05, 0.5, 100, C_cls=Cn)
+        n = int(num[b])
+        assert n == o['num_det']
+        assert np.array_equal(labels[b, :n].cpu().numpy(), o['det_labels'])
+        assert np.array_equal(rows[b, :n].cpu().numpy(), o['det_rows'])
+        assert G.same_bits(dets[b, :n].cpu().numpy(), o['det_bboxes'])

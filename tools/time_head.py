@@ -25,6 +25,11 @@ for (h, w) in synth.level_shapes(ph, pw):
         cls.append(torch.randn(B, 720, h, w, device='cuda', generator=g) * sd + mu)
         reg.append(torch.randn(B, 36, h, w, device='cuda', generator=g) * rsd)
         iou.append(torch.randn(B, 9, h, w, device='cuda', generator=g) * isd)
+if os.environ.get('CL', '1') != '0':      # channels-last head outputs (what bench.py's model produces)
+    cls, reg, iou = [[t.contiguous(memory_format=torch.channels_last) for t in x]
+                     for x in (cls, reg, iou)]
+geom = ops.geometry_for(geom, cls, reg, iou)
+print('layout', 'NHWC' if geom.layout else 'NCHW')
 shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
 def stage_times():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
