@@ -55,7 +55,11 @@ def _bottleneck_forward(self, x):
         return type(self).forward(self, x)
     f = self._ia_fused
     out = ops.channel_affine_act_(self.conv1(x), f['s1'], f['b1'], relu=True)
-    out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
+    wino = f.get('wino2')
+    if wino is not None and wino.usable(out):
+        out = wino(out)                       # conv2 + folded BN + ReLU in the Winograd path
+    else:
+        out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
     out = self.conv3(out)
     if self.downsample is None:
         return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True)
@@ -95,6 +99,9 @@ def _convmodule_forward(self, x, activate=True, norm=True):
         return type(self).forward(self, x, activate, norm)
     f = self._ia_fused
     relu = bool(activate and self.with_activatation)
+    wino = f.get('wino')
+    if wino is not None and wino.relu == relu and wino.usable(x):
+        return wino(x)
     if self.with_norm and norm:
         y = self.conv(x)                      # conv before a norm has no bias
         return ops.channel_affine_act_(y, f['s'], f['b'], relu=relu)
@@ -111,6 +118,12 @@ def _head_forward(self, feats):
     return type(self).forward(self, feats)
 
 
+def _wino_ok(conv):
+    return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0)
+
+
 def fuse_inference(model, winograd=False):
     """Patch `model` in place (see module docstring).  Returns the number of fused modules.
 
@@ -118,6 +131,13 @@ def fuse_inference(model, winograd=False):
     F(4x4,3x3) path (iouaware/winograd.py) whenever its inputs are channels-last fp32 CUDA
     tensors: all pyramid levels in one batched GEMM per layer."""
     n = 0
+    # FPN output convolutions (per-level weights) take the single-level Winograd path; the head's
+    # ConvModules are bypassed by the head-level runner below
+    fpn_convs = set()
+    if winograd:
+        for m in model.modules():
+            if type(m).__name__ == 'FPN':
+                fpn_convs.update(id(c) for c in m.fpn_convs)
     for m in model.modules():
         if winograd and type(m).__name__ == 'IoUawareRetinaHead':
             from .winograd import WinogradHead
@@ -132,6 +152,11 @@ def fuse_inference(model, winograd=False):
             f['s3'], f['b3'] = _fold_bn(m.norm3)
             if m.downsample is not None:
                 f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+            if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
+                from .winograd import WinogradConv3x3
+                with torch.no_grad():           # BN scale folded into the weights, shift = bias
+                    w2 = m.conv2.weight.float() * f['s2'].view(-1, 1, 1, 1)
+                f['wino2'] = WinogradConv3x3(w2, f['b2'], relu=True)
             m._ia_fused = f
             m.forward = types.MethodType(_bottleneck_forward, m)
         elif isinstance(m, BasicBlock):
@@ -155,6 +180,9 @@ def fuse_inference(model, winograd=False):
                 f['s'], f['b'] = _fold_bn(m.norm)
             elif m.conv.bias is not None:
                 f['bias'] = m.conv.bias.detach().float().contiguous()
+            if winograd and id(m) in fpn_convs and not m.with_norm and _wino_ok(m.conv):
+                from .winograd import WinogradConv3x3
+                f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)
             m._ia_fused = f
             m.forward = types.MethodType(_convmodule_forward, m)
         else:

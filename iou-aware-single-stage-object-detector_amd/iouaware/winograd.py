@@ -52,6 +52,22 @@ def _usable(x):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, name, shape):
+    """V / M staging buffers are shared by every Winograd layer of the process: the layers run
+    one after the other on one stream, so a buffer is free again when the next layer starts."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    key = (device, torch.cuda.current_stream().cuda_stream, name)
+    b = _SCRATCH.get(key)
+    if b is None or b.numel() < n:
+        b = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return b[:n].view(*shape)
+
+
 class _Plan(object):
     """buffers of one (batch, feature-map sizes) configuration"""
 
@@ -62,11 +78,7 @@ class _Plan(object):
         self._bufs = {}
 
     def buf(self, name, shape):
-        b = self._bufs.get(name)
-        if b is None or tuple(b.shape) != tuple(shape):
-            b = torch.empty(shape, dtype=torch.float32, device=self.device)
-            self._bufs[name] = b
-        return b
+        return _scratch(self.device, name, shape)
 
     def acts(self, name, channels):
         """per-level channels-last activation tensors (B, C, H, W)"""
@@ -114,6 +126,9 @@ class WinogradConv3x3(object):
         if self.cout % 4:
             raise ValueError('output channels must be a multiple of 4')
         self._plans = {}
+
+    def usable(self, x):
+        return _usable(x) and x.shape[1] == self.cin and not torch.is_grad_enabled()
 
     def __call__(self, x):
         key = (x.shape[0], tuple(x.shape[-2:]), x.device)
@@ -190,8 +205,8 @@ class WinogradHead(object):
             plan = self._plans[key] = _Plan(sizes, B, feats[0].device)
         T, F = plan.T, self.F
         # layer 0
-        v = input_transform(plan, feats, 1, plan.buf('v0', (36, T, self.cin)))
-        m = torch.bmm(v, self.u0, out=plan.buf('m0', (36, T, 2 * F)))
+        v = input_transform(plan, feats, 1, plan.buf('v', (36, T, self.cin)))
+        m = torch.bmm(v, self.u0, out=plan.buf('m', (36, T, 2 * F)))
         acts = plan.acts('a', 2 * F)
         output_transform(plan, m, 2 * F, 1, self.b0, True, [(0, 2 * F, acts, 0)])
         # layers 1..n-1: groups = 2 (cls tower = channels [0,F), reg tower = [F,2F))

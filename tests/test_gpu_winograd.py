@@ -74,3 +74,39 @@ def test_head_matches_module_forward_and_detections():
     for d, d0 in zip(dets, dets0):          # per-class lists; boxes within 1e-3 px, same counts
         n = sum(len(x) for x in d)
         assert n == sum(len(x) for x in d0) and n > 0
+
+
+def test_whole_network_winograd_matches_module_path():
+    """fuse_inference(winograd=True): Bottleneck 3x3 convs (BN folded into the weights), FPN output
+    convs and the head -- against the plain nn.Module forward of the same weights"""
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    import bench
+    torch.manual_seed(0)
+    m = iouaware.build_detector(ConfigDict(bench.MODEL), test_cfg=ConfigDict(bench.TEST_CFG)).cuda().eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.1)
+        for p in m.bbox_head.parameters():
+            if p.dim() == 4:
+                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
+    m = m.to(memory_format=torch.channels_last)
+    x = _cl(torch.randn(2, 3, 224, 288, device='cuda'))
+    with torch.no_grad():
+        ref = m.forward_head(x)
+        n = fuse_inference(m, winograd=True)
+        wino_blocks = [b for b in m.backbone.modules() if getattr(b, '_ia_fused', {}).get('wino2')]
+        assert len(wino_blocks) == 13                      # 16 bottlenecks - 3 with a stride-2 conv2
+        assert sum(1 for c in m.neck.fpn_convs if c._ia_fused.get('wino')) == 3
+        out = m.forward_head(x)
+        unfuse_inference(m)
+    for a, b in zip(ref, out):
+        for u, v in zip(a, b):
+            assert v.is_contiguous(memory_format=torch.channels_last)
+            e = float((u - v).abs().max() / u.abs().max())
+            assert e < 1e-4, e
