@@ -196,11 +196,24 @@ typedef struct {
     float *dst[IA_MAX_LEVELS];      /* per level (B, H_l, W_l, dst_channels)               */
 } ia_wino_seg;
 int ia_wino_tiles(const ia_wino_geom *g, int32_t *tiles);
+/* pre_shift != NULL: the input is read as relu?(x * pre_scale[c] + pre_shift[c]) (pre_scale
+ * NULL = 1): the folded BatchNorm + ReLU of the producing 1x1 convolution, applied on load.  */
 int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int channels, int groups,
-                            float *V, void *stream);
+                            const float *pre_scale, const float *pre_shift, int pre_relu, float *V,
+                            void *stream);
 int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels, int groups,
                              const float *bias, int relu, int nseg, const ia_wino_seg *segs,
                              void *stream);
+
+/* 1x1 convolution on a channels-last activation as one library GEMM (hipBLASLt) with the folded
+ * BatchNorm bias, the residual and the ReLU in its epilogue (Bottleneck.forward,
+ * mmdet/models/backbones/resnet.py:215-255, at inference):
+ *   D (rows, n) = act(A (rows, k) . W (k, n) + bias[n] + residual (rows, n)),  rows = B*H*W
+ * all row-major fp32; bias / residual optional; residual != D.  The library handle is created on
+ * first use; the first call of a shape times the heuristic's candidates on `stream`.         */
+int ia_linear_bias_act(const float *A, const float *W, const float *bias, const float *residual,
+                       float *D, int64_t rows, int k, int n, int relu, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on

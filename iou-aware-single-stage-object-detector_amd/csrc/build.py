@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['capi.hip', 'decode.hip', 'select.hip', 'nms.hip', 'loss.hip', 'elementwise.hip', 'assign.hip',
-           'softnms.hip', 'preproc.hip', 'wino.hip']
+           'softnms.hip', 'preproc.hip', 'wino.hip', 'gemm.hip']
 HEADERS = ['ia_math.hpp', 'ia_block.hpp', 'ia_internal.hpp', '../../include/iouaware.h']
 OUT = os.path.join(HERE, 'libiouaware_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
@@ -53,7 +53,10 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode()))
         if verbose and out:
             print(out.decode())
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    # gemm.hip calls hipBLASLt (library GEMM with fused epilogue); inside a torch process the
+    # loader resolves libhipblaslt.so.1 to the copy torch already mapped
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + [
+        '-L/opt/rocm/lib', '-lhipblaslt', '-Wl,-rpath,/opt/rocm/lib']
     subprocess.run(cmd, check=True)
     return OUT
 

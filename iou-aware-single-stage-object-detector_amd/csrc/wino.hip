@@ -95,7 +95,11 @@ struct WinoInArgs {
     WinoLevels lv;
     const float *x[IA_MAX_LEVELS];        // per level (B, H, W, Ctot) channels-last
     float *V;                             // (groups * 36, T, Cg)
-    int32_t Ctot, Cg, T;
+    // optional pre-activation of the input: relu(x * scale[c] + shift[c]) -- the folded
+    // BatchNorm + ReLU of the 1x1 convolution in front, applied on load instead of in a pass
+    // of its own; padding stays zero
+    const float *pre_scale, *pre_shift;
+    int32_t Ctot, Cg, T, pre_relu;
 };
 
 __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
@@ -106,6 +110,12 @@ __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
     const TileRef r = locate_tile(a.lv, t);
     const int H = a.lv.H[r.l], W = a.lv.W[r.l];
     const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
+    const bool pre = a.pre_shift != nullptr;
+    float4 ps = f4(1.0f), pb = f4(0.0f);
+    if (pre) {
+        if (a.pre_scale) ps = *reinterpret_cast<const float4 *>(a.pre_scale + c);
+        pb = *reinterpret_cast<const float4 *>(a.pre_shift + c);
+    }
     float4 d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -118,7 +128,12 @@ __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
             const bool in = yin && (xx >= 0) && (xx < W);
             const int xc = (xx >= 0 && xx < W) ? xx : 0;
             // the load is unconditional (clamped address); padding is selected afterwards
-            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
+            float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
+            if (pre) {
+                v = make_float4(v.x * ps.x + pb.x, v.y * ps.y + pb.y, v.z * ps.z + pb.z, v.w * ps.w + pb.w);
+                if (a.pre_relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f,
+                                                v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+            }
             d[i][j] = in ? v : f4(0.0f);
         }
     }
@@ -233,7 +248,8 @@ int ia_wino_tiles(const ia_wino_geom *g, int32_t *tiles)
 }
 
 int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int channels, int groups,
-                            float *V, void *stream)
+                            const float *pre_scale, const float *pre_shift, int pre_relu, float *V,
+                            void *stream)
 {
     ia::WinoInArgs a;
     int rc = ia::make_wino_levels(g, a.lv);
@@ -246,6 +262,8 @@ int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int ch
         if (l < a.lv.L && (!x[l] || ((uintptr_t)x[l] & 15u))) return IA_E_ARG;
     }
     a.V = V;
+    if (pre_scale && !pre_shift) return IA_E_ARG;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu ? 1 : 0;
     dim3 grid((unsigned)a.T, (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());

@@ -76,9 +76,11 @@ SIGNATURES = {
     'ia_image_transform': (_i, [C.POINTER(ImageDesc), _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                 _i, _i, _i, _i, _vp, _vp]),
     'ia_wino_tiles': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_int32)]),
-    'ia_wino_input_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _i, _vp, _vp]),
+    'ia_wino_input_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _i, _vp, _vp, _i,
+                                     _vp, _vp]),
     'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
                                       C.POINTER(WinoSeg), _vp]),
+    'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

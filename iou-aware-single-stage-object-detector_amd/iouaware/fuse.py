@@ -54,12 +54,30 @@ def _bottleneck_forward(self, x):
     if not _fast(self, x):
         return type(self).forward(self, x)
     f = self._ia_fused
-    out = ops.channel_affine_act_(self.conv1(x), f['s1'], f['b1'], relu=True)
+    lt = 'w1' in f and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    if lt:
+        # 1x1 convolutions = library GEMMs on the channels-last activation, folded BN / residual /
+        # ReLU in the GEMM epilogue (csrc/gemm.hip)
+        out, pre = ops.linear_bias_act(x, f['w1'], f['b1'], relu=True), None
+    else:
+        out, pre = self.conv1(x), (f['s1'], f['b1'], True)
     wino = f.get('wino2')
     if wino is not None and wino.usable(out):
-        out = wino(out)                       # conv2 + folded BN + ReLU in the Winograd path
+        # (conv1's BN + ReLU on load,) conv2 + its folded BN + ReLU in the Winograd path
+        out = wino(out, pre=pre)
     else:
+        if pre is not None:
+            out = ops.channel_affine_act_(out, f['s1'], f['b1'], relu=True)
         out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
+    if lt and out.is_contiguous(memory_format=torch.channels_last):
+        if self.downsample is None:
+            return ops.linear_bias_act(out, f['w3'], f['b3'], residual=x, relu=True)
+        if 'wd' in f:                     # stride-1 projection: a GEMM as well
+            idn = ops.linear_bias_act(x, f['wd'], f['b3d'])
+            return ops.linear_bias_act(out, f['w3'], None, residual=idn, relu=True)
+        ds = self.downsample[0]
+        idn = F.conv2d(x, f['wd_conv'], None, ds.stride, ds.padding)
+        return ops.linear_bias_act(out, f['w3'], f['b3d'], residual=idn, relu=True)
     out = self.conv3(out)
     if self.downsample is None:
         return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True)
@@ -124,6 +142,11 @@ def _wino_ok(conv):
             and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0)
 
 
+def _gemm_ok(conv):
+    return (tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.bias is None)
+
+
 def fuse_inference(model, winograd=False):
     """Patch `model` in place (see module docstring).  Returns the number of fused modules.
 
@@ -152,6 +175,20 @@ def fuse_inference(model, winograd=False):
             f['s3'], f['b3'] = _fold_bn(m.norm3)
             if m.downsample is not None:
                 f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+            if winograd and _gemm_ok(m.conv1) and _gemm_ok(m.conv3):
+                with torch.no_grad():
+                    def kn(conv, scale):       # (Cout, Cin, 1, 1) * scale[Cout] -> (Cin, Cout)
+                        w = conv.weight.float().view(conv.out_channels, conv.in_channels)
+                        return (w * scale.view(-1, 1)).t().contiguous()
+                    f['w1'], f['w3'] = kn(m.conv1, f['s1']), kn(m.conv3, f['s3'])
+                    if m.downsample is not None:
+                        ds = m.downsample[0]
+                        f['b3d'] = (f['b3'] + f['bd']).contiguous()
+                        if _gemm_ok(ds):
+                            f['wd'] = kn(ds, f['sd'])
+                        else:
+                            f['wd_conv'] = (ds.weight.float() * f['sd'].view(-1, 1, 1, 1)).contiguous(
+                                memory_format=torch.channels_last)
             if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
                 from .winograd import WinogradConv3x3
                 with torch.no_grad():           # BN scale folded into the weights, shift = bias

@@ -387,6 +387,31 @@ def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None
     return x
 
 
+_LT_WS_BYTES = 64 << 20
+
+
+def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False):
+    """1x1 convolution of a channels-last (B, k, H, W) fp32 tensor as one hipBLASLt GEMM:
+    relu?(x . w_kn + bias + residual) -> channels-last (B, n, H, W).  w_kn: (k, n) row-major."""
+    _require_gpu(x, 'x')
+    B, k, H, W = x.shape
+    n = int(w_kn.shape[1])
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('linear_bias_act needs a channels-last fp32 activation')
+    if tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous():
+        raise ValueError('weight must be a contiguous (k, n) matrix')
+    out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device,
+                      memory_format=torch.channels_last)
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('residual must be a channels-last tensor of the output shape')
+    ws = _workspace(x.device, _LT_WS_BYTES)
+    _lib.check(_lib.lib().ia_linear_bias_act(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual),
+                                             _ptr(out), B * H * W, k, n, int(bool(relu)), _ptr(ws),
+                                             _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')
+    return out
+
+
 def test_math(op, x, y=None):
     _require_gpu(x, 'x')
     x = x.contiguous()

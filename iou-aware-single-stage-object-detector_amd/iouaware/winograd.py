@@ -91,10 +91,13 @@ class _Plan(object):
         return a
 
 
-def input_transform(plan, xs, groups, out):
+def input_transform(plan, xs, groups, out, pre=None):
+    """pre = (scale or None, shift, relu): the input is read as relu?(x * scale + shift)"""
     ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    ps, pb, pr = pre if pre is not None else (None, None, False)
     _lib.check(_lib.lib().ia_wino_input_transform(C.byref(plan.geom), ptrs, int(xs[0].shape[1]),
-                                                  int(groups), _ptr(out), _stream()),
+                                                  int(groups), _ptr(ps), _ptr(pb), int(bool(pr)),
+                                                  _ptr(out), _stream()),
                'ia_wino_input_transform')
     return out
 
@@ -130,12 +133,14 @@ class WinogradConv3x3(object):
     def usable(self, x):
         return _usable(x) and x.shape[1] == self.cin and not torch.is_grad_enabled()
 
-    def __call__(self, x):
+    def __call__(self, x, pre=None):
+        """pre = (scale, shift, relu): x is the raw output of the convolution in front, its folded
+        BatchNorm / ReLU is applied while the input transform loads it"""
         key = (x.shape[0], tuple(x.shape[-2:]), x.device)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = _Plan([tuple(x.shape[-2:])], x.shape[0], x.device)
-        v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)))
+        v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)), pre)
         m = torch.bmm(v, self.u, out=plan.buf('m', (36, plan.T, self.cout)))
         y = torch.empty((x.shape[0], self.cout) + tuple(x.shape[-2:]), dtype=torch.float32,
                         device=x.device, memory_format=torch.channels_last)

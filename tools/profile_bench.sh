@@ -18,6 +18,8 @@ grep "^{" /tmp/prof_bench.log > $OUT/bench.json
 head -60 /tmp/prof_bench/*/*_kernel_stats.csv | cut -c1-260 > $OUT/kernel_stats.csv
 grep "ia::" /tmp/prof_bench/*/*_kernel_stats.csv > $OUT/kernel_stats_ia.csv
 python $ROOT/tools/summarize_trace.py /tmp/prof_bench/*/*_kernel_trace.csv --steps 5 > $OUT/step_summary.txt
-bash $ROOT/tools/collect_pmc.sh 8 D > /tmp/pmc.log 2>&1
-cp $ROOT/gpurun_out/pmc/head_pmc.json $OUT/head_pmc.json
+if [ -z "$SKIP_PMC" ]; then
+  bash $ROOT/tools/collect_pmc.sh 8 D > /tmp/pmc.log 2>&1
+  cp $ROOT/gpurun_out/pmc/head_pmc.json $OUT/head_pmc.json
+fi
 cat $OUT/bench.json | cut -c1-600; cat $OUT/kernel_stats_ia.csv | cut -d, -f1-4; head -24 $OUT/step_summary.txt | cut -c1-150
