@@ -18,7 +18,7 @@ namespace ia {
 struct LtState {
     hipblasLtHandle_t handle = nullptr;
     std::mutex mu;
-    std::map<std::tuple<int64_t, int, int, int>, hipblasLtMatmulAlgo_t> algos;
+    std::map<std::tuple<int64_t, int, int, int, int>, hipblasLtMatmulAlgo_t> algos;
 };
 
 static LtState &lt_state()
@@ -29,13 +29,13 @@ static LtState &lt_state()
 
 static int lt_status(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS ? 0 : 2000 + (int)s; }
 
-}  // namespace ia
-
-extern "C" int ia_linear_bias_act(const float *A, const float *W, const float *bias,
-                                  const float *residual, float *D, int64_t rows, int k, int n,
-                                  int relu, void *workspace, size_t workspace_bytes, void *stream)
+// batch > 1: strided batched, A / W / D advance by rows*k / k*n / rows*n per matrix
+static int lt_matmul(const float *A, const float *W, const float *bias, const float *residual,
+                     float *D, int64_t rows, int k, int n, int relu, int batch, void *workspace,
+                     size_t workspace_bytes, void *stream)
 {
-    if (!A || !W || !D || rows < 1 || k < 1 || n < 1 || residual == D || A == D) return IA_E_ARG;
+    if (!A || !W || !D || rows < 1 || k < 1 || n < 1 || batch < 1 || residual == D || A == D)
+        return IA_E_ARG;
     if (workspace_bytes && !workspace) return IA_E_ARG;
     ia::LtState &st = ia::lt_state();
     std::lock_guard<std::mutex> lock(st.mu);
@@ -66,18 +66,29 @@ extern "C" int ia_linear_bias_act(const float *A, const float *W, const float *b
     IA_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_32F, (uint64_t)n, (uint64_t)k, (int64_t)n));
     IA_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_32F, (uint64_t)k, (uint64_t)rows, (int64_t)k));
     IA_LT(hipblasLtMatrixLayoutCreate(&lc, HIP_R_32F, (uint64_t)n, (uint64_t)rows, (int64_t)n));
+    if (batch > 1) {
+        const int32_t bc = batch;
+        const int64_t sa = (int64_t)k * n, sb = rows * k, sc = rows * n;
+        hipblasLtMatrixLayout_t ls[3] = {la, lb, lc};
+        const int64_t so[3] = {sa, sb, sc};
+        for (int i = 0; i < 3; ++i) {
+            IA_LT(hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)));
+            IA_LT(hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET,
+                                                    &so[i], sizeof(so[i])));
+        }
+    }
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
     const float *C = residual ? residual : D;
     const int flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (residual ? 4 : 0);
-    const auto key = std::make_tuple(rows, k, n, flags);
+    const auto key = std::make_tuple(rows, k, n, flags, batch);
     auto it = st.algos.find(key);
     if (it == st.algos.end()) {
         IA_LT(hipblasLtMatmulPreferenceCreate(&pref));
         IA_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
                                                     &workspace_bytes, sizeof(workspace_bytes)));
-        hipblasLtMatmulHeuristicResult_t res[6];
+        hipblasLtMatmulHeuristicResult_t res[16];
         int nres = 0;
-        IA_LT(hipblasLtMatmulAlgoGetHeuristic(st.handle, desc, la, lb, lc, lc, pref, 6, res, &nres));
+        IA_LT(hipblasLtMatmulAlgoGetHeuristic(st.handle, desc, la, lb, lc, lc, pref, 16, res, &nres));
         if (nres < 1) { cleanup(); return IA_E_ARG; }
         // first call of this shape: time the candidates on the caller's stream (the output is
         // simply rewritten; C != D, so every run computes the same result)
@@ -110,4 +121,21 @@ extern "C" int ia_linear_bias_act(const float *A, const float *W, const float *b
 #undef IA_LT
     cleanup();
     return rc;
+}
+
+}  // namespace ia
+
+extern "C" int ia_linear_bias_act(const float *A, const float *W, const float *bias,
+                                  const float *residual, float *D, int64_t rows, int k, int n,
+                                  int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return ia::lt_matmul(A, W, bias, residual, D, rows, k, n, relu, 1, workspace, workspace_bytes,
+                         stream);
+}
+
+extern "C" int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows,
+                               int k, int n, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return ia::lt_matmul(A, W, nullptr, nullptr, D, rows, k, n, 0, batch, workspace,
+                         workspace_bytes, stream);
 }

@@ -65,6 +65,18 @@ __device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t)
     return r;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// streaming accesses: V is written once and read by the GEMM much later, M is read exactly once
+__device__ __forceinline__ float4 load_nt(const float *p)
+{
+    const f32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ void store_nt(float *p, const float4 &v)
+{
+    f32x4_t q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    __builtin_nontemporal_store(q, reinterpret_cast<f32x4_t *>(p));
+}
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 operator+(const float4 &a, const float4 &b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator-(const float4 &a, const float4 &b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
     for (int j = 0; j < 6; ++j) {                       // columns: s = A^T m
         float4 col[6], o[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4 *>(m + (size_t)(i * 6 + j) * kstride);
+        for (int i = 0; i < 6; ++i) col[i] = load_nt(m + (size_t)(i * 6 + j) * kstride);
         at6(col, o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][j] = o[i];

@@ -3,7 +3,7 @@ RetinaNet head (reference iou_aware_retina_head.py:171-219: cls / reg towers, re
 retina_reg, retina_iou) and of the FPN output convolutions (fpn.py:124-127).
 
     activations (channels-last, all five levels)  --k_wino_in-->   V  (36 matrices tiles x Cin)
-    V . U   (36 [x2 towers] plain fp32 GEMMs, torch.bmm -> rocBLAS / hipBLASLt)  -->  M
+    V . U   (36 [x2 towers] plain fp32 GEMMs: hipBLASLt, strided batched, csrc/gemm.hip)    -->  M
     M  --k_wino_out (+bias, +ReLU)-->  next activations / the head outputs, channels-last
 
 The head's weights are shared by the pyramid levels, so every layer is ONE batched GEMM over the
@@ -116,6 +116,23 @@ def output_transform(plan, m, channels, groups, bias, relu, segments):
                'ia_wino_output_transform')
 
 
+_LT_WS_BYTES = 128 << 20
+
+
+def batched_gemm(v, u, out):
+    """out[b] = v[b] @ u[b] through hipBLASLt (csrc/gemm.hip): the first call of a shape times the
+    library's candidate kernels, which is worth ~20 % over the default pick at these shapes"""
+    batch, rows, k = v.shape
+    n = u.shape[2]
+    if not (v.is_contiguous() and u.is_contiguous() and out.is_contiguous()):
+        raise ValueError('batched_gemm needs contiguous stacks')
+    ws = _scratch(v.device, 'lt_ws', (_LT_WS_BYTES // 4,))
+    _lib.check(_lib.lib().ia_batched_gemm(_ptr(v), _ptr(u), _ptr(out), int(batch), int(rows), int(k),
+                                          int(n), _ptr(ws), _LT_WS_BYTES, _stream()),
+               'ia_batched_gemm')
+    return out
+
+
 class WinogradConv3x3(object):
     """one 3x3 / stride-1 / pad-1 convolution (+bias, +ReLU) over a list of channels-last level
     tensors that do NOT share the weight with other layers' inputs (FPN output convs: one
@@ -141,7 +158,7 @@ class WinogradConv3x3(object):
         if plan is None:
             plan = self._plans[key] = _Plan([tuple(x.shape[-2:])], x.shape[0], x.device)
         v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)), pre)
-        m = torch.bmm(v, self.u, out=plan.buf('m', (36, plan.T, self.cout)))
+        m = batched_gemm(v, self.u, plan.buf('m', (36, plan.T, self.cout)))
         y = torch.empty((x.shape[0], self.cout) + tuple(x.shape[-2:]), dtype=torch.float32,
                         device=x.device, memory_format=torch.channels_last)
         output_transform(plan, m, self.cout, 1, self.bias, self.relu, [(0, self.cout, [y], 0)])
@@ -211,20 +228,20 @@ class WinogradHead(object):
         T, F = plan.T, self.F
         # layer 0
         v = input_transform(plan, feats, 1, plan.buf('v', (36, T, self.cin)))
-        m = torch.bmm(v, self.u0, out=plan.buf('m', (36, T, 2 * F)))
+        m = batched_gemm(v, self.u0, plan.buf('m', (36, T, 2 * F)))
         acts = plan.acts('a', 2 * F)
         output_transform(plan, m, 2 * F, 1, self.b0, True, [(0, 2 * F, acts, 0)])
         # layers 1..n-1: groups = 2 (cls tower = channels [0,F), reg tower = [F,2F))
         for u, b in zip(self.u, self.b):
             v = input_transform(plan, acts, 2, plan.buf('v', (72, T, F)))
-            m = torch.bmm(v, u, out=plan.buf('m', (72, T, F)))
+            m = batched_gemm(v, u, plan.buf('m', (72, T, F)))
             nxt = plan.acts('b' if acts is plan.acts('a', 2 * F) else 'a', 2 * F)
             output_transform(plan, m, 2 * F, 2, b, True, [(0, 2 * F, nxt, 0)])
             acts = nxt
         # outputs
         v = input_transform(plan, acts, 2, plan.buf('v', (72, T, F)))
-        m_cls = torch.bmm(v[:36], self.u_cls, out=plan.buf('mc', (36, T, self.c_cls)))
-        m_ri = torch.bmm(v[36:], self.u_ri, out=plan.buf('mr', (36, T, self.n_ri_pad)))
+        m_cls = batched_gemm(v[:36], self.u_cls, plan.buf('mc', (36, T, self.c_cls)))
+        m_ri = batched_gemm(v[36:], self.u_ri, plan.buf('mr', (36, T, self.n_ri_pad)))
         new = lambda c: [torch.empty((B, c, h, w), dtype=torch.float32, device=feats[0].device,  # noqa: E731
                                      memory_format=torch.channels_last) for (h, w) in sizes]
         cls, reg, iou = new(self.c_cls), new(self.c_reg), new(self.c_iou)
