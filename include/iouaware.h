@@ -336,6 +336,12 @@ int ia_channel_affine_act_nhwc(void *x, int dtype, const float *scale, const flo
  * convolutions run in MIOpen's NHWC kernels while the head kernels read NCHW.    */
 int ia_nhwc_to_nchw(const void *src, void *dst, int dtype, int N, int C, int64_t HW, void *stream);
 
+/* ResNet stem at inference (mmdet/models/backbones/resnet.py:506-512): folded BatchNorm + ReLU +
+ * MaxPool2d(kernel 3, stride 2, padding 1) in one pass.  x (B,H,W,C) channels-last fp32, C % 4 == 0;
+ * out (B, (H-1)/2+1, (W-1)/2+1, C).                                                          */
+int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int B, int H,
+                                int W, int C, float *out, void *stream);
+
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the
  * device implementation bit-for-bit: op 0 exp, 1 log, 2 sigmoid, 3 sqrt,

@@ -103,7 +103,13 @@ def _resnet_forward(self, x):
     if not _fast(self, x):
         return type(self).forward(self, x)
     f = self._ia_fused
-    x = self.maxpool(ops.channel_affine_act_(self.conv1(x), f['s'], f['b'], relu=True))
+    x = self.conv1(x)
+    mp = self.maxpool
+    if f.get('pool') and x.dtype == torch.float32 and x.shape[1] % 4 == 0 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        x = ops.affine_relu_maxpool(x, f['s'], f['b'])          # BN + ReLU + 3x3/2 max-pool, one pass
+    else:
+        x = mp(ops.channel_affine_act_(x, f['s'], f['b'], relu=True))
     outs = []
     for i, name in enumerate(self.res_layers):
         x = getattr(self, name)(x)
@@ -120,6 +126,9 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     wino = f.get('wino')
     if wino is not None and wino.relu == relu and wino.usable(x):
         return wino(x)
+    if 'w_kn' in f and norm and x.dtype == torch.float32 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        return ops.linear_bias_act(x, f['w_kn'], f['b_kn'], relu=relu)      # 1x1 conv = GEMM
     if self.with_norm and norm:
         y = self.conv(x)                      # conv before a norm has no bias
         return ops.channel_affine_act_(y, f['s'], f['b'], relu=relu)
@@ -140,6 +149,10 @@ def _wino_ok(conv):
     return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
             and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1)
             and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0)
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
 def _gemm_ok(conv):
@@ -207,6 +220,9 @@ def fuse_inference(model, winograd=False):
         elif isinstance(m, ResNet):
             f = {}
             f['s'], f['b'] = _fold_bn(m.norm1)
+            mp = m.maxpool
+            f['pool'] = (_pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding),
+                         _pair(mp.dilation), mp.ceil_mode) == ((3, 3), (2, 2), (1, 1), (1, 1), False)
             m._ia_fused = f
             m.forward = types.MethodType(_resnet_forward, m)
         elif isinstance(m, ConvModule):
@@ -217,6 +233,16 @@ def fuse_inference(model, winograd=False):
                 f['s'], f['b'] = _fold_bn(m.norm)
             elif m.conv.bias is not None:
                 f['bias'] = m.conv.bias.detach().float().contiguous()
+            c = m.conv
+            if winograd and tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) \
+                    and tuple(c.padding) == (0, 0) and c.groups == 1:
+                with torch.no_grad():
+                    w = c.weight.float().view(c.out_channels, c.in_channels)
+                    if m.with_norm:
+                        f['w_kn'], f['b_kn'] = (w * f['s'].view(-1, 1)).t().contiguous(), f['b']
+                    else:
+                        f['w_kn'] = w.t().contiguous()
+                        f['b_kn'] = None if c.bias is None else c.bias.detach().float().contiguous()
             if winograd and id(m) in fpn_convs and not m.with_norm and _wino_ok(m.conv):
                 from .winograd import WinogradConv3x3
                 f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)

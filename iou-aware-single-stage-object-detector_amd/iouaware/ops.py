@@ -387,6 +387,20 @@ def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None
     return x
 
 
+def affine_relu_maxpool(x, scale, shift):
+    """relu(x * scale + shift) followed by MaxPool2d(3, 2, 1) on a channels-last fp32 tensor"""
+    _require_gpu(x, 'x')
+    B, Cn, H, W = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) or Cn % 4:
+        raise TypeError('affine_relu_maxpool needs a channels-last fp32 tensor, C % 4 == 0')
+    out = torch.empty((B, Cn, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32,
+                      device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().ia_affine_relu_maxpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), B, H, W, Cn,
+                                                      _ptr(out), _stream()),
+               'ia_affine_relu_maxpool_nhwc')
+    return out
+
+
 _LT_WS_BYTES = 64 << 20
 
 

@@ -89,3 +89,37 @@ def test_nhwc_to_nchw_and_channels_last_epilogue(shape, dtype):
                                     residual=r.contiguous(memory_format=torch.channels_last),
                                     relu=True)
         assert c.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 400, 672), (1, 64, 37, 53), (3, 8, 5, 4), (2, 16, 1, 1)])
+def test_affine_relu_maxpool_matches_torch(shape):
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(*shape, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    s = torch.randn(shape[1], device='cuda', generator=g)        # negative scales included
+    t = torch.randn(shape[1], device='cuda', generator=g)
+    got = ops.affine_relu_maxpool(x, s, t)
+    want = torch.nn.functional.max_pool2d(torch.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)),
+                                          3, 2, 1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+def test_linear_bias_act_matches_conv():
+    """hipBLASLt 1x1-conv GEMM with bias / residual / ReLU in the epilogue vs conv2d + torch ops"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(2, 64, 50, 84, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(256, 64, 1, 1, device='cuda', generator=g) * 0.1
+    b = torch.randn(256, device='cuda', generator=g)
+    r = torch.randn(2, 256, 50, 84, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w_kn = w.view(256, 64).t().contiguous()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    for res, relu in ((None, False), (None, True), (r, True), (r, False)):
+        want = ref + (res.double() if res is not None else 0)
+        want = want.clamp(min=0) if relu else want
+        got = ops.linear_bias_act(x, w_kn, b, residual=res, relu=relu)
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+    got = ops.linear_bias_act(x, w_kn, None)
+    assert float((got.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) < 1e-4 * float(ref.abs().max())
