@@ -52,6 +52,17 @@ static int make_wino_levels(const ia_wino_geom *g, WinoLevels &w)
 
 struct TileRef { int l, b, y0, x0; };
 
+// Workgroup id -> tile.  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin and
+// every XCD has its own L2: with the identity mapping the tiles that share input pixels (a tile
+// overlaps its neighbours by two rows / columns, 2.25 reads per pixel) would sit in eight
+// different L2s and the overlap would be fetched from HBM again.  Give each XCD one contiguous
+// range of tiles instead.
+__device__ __forceinline__ int xcd_tile(int bid, int T)
+{
+    const int per = (T + 7) / 8;
+    return (bid & 7) * per + (bid >> 3);
+}
+
 __device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t)
 {
     TileRef r;
@@ -116,9 +127,9 @@ struct WinoInArgs {
 
 __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
 {
-    const int t = blockIdx.x;
+    const int t = xcd_tile(blockIdx.x, a.T);
     const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
-    if (c >= a.Ctot) return;
+    if (c >= a.Ctot || t >= a.T) return;
     const TileRef r = locate_tile(a.lv, t);
     const int H = a.lv.H[r.l], W = a.lv.W[r.l];
     const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
@@ -189,9 +200,9 @@ struct WinoOutArgs {
 
 __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
 {
-    const int t = blockIdx.x;
+    const int t = xcd_tile(blockIdx.x, a.T);
     const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
-    if (c >= a.Ctot) return;
+    if (c >= a.Ctot || t >= a.T) return;
     const TileRef r = locate_tile(a.lv, t);
     const int H = a.lv.H[r.l], W = a.lv.W[r.l];
     const int g = c / a.Cg, cc = c - g * a.Cg;
@@ -276,7 +287,7 @@ int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int ch
     a.V = V;
     if (pre_scale && !pre_shift) return IA_E_ARG;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu ? 1 : 0;
-    dim3 grid((unsigned)a.T, (unsigned)((channels / 4 + 63) / 64));
+    dim3 grid((unsigned)((a.T + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
@@ -307,7 +318,7 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
             a.seg[k].dst[l] = s.dst[l];
         }
     }
-    dim3 grid((unsigned)a.T, (unsigned)((channels / 4 + 63) / 64));
+    dim3 grid((unsigned)((a.T + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_out, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
