@@ -7,16 +7,19 @@ IoU-aware RetinaNet R-50-FPN (fp32), batch 8 per GPU on MI355X.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole inference path over one batch of synthetic
-COCO-shaped input already resident in HBM: ResNet-50 + FPN + head convolutions
-(PyTorch-ROCm / MIOpen) -> HIP row-max / top-k / gather+decode / batched NMS /
-final top-100 -> (N>1) one RCCL all-gather of the per-image detections.
+COCO-shaped input already resident in HBM: ResNet-50 + FPN + head convolutions, fp32,
+channels-last (3x3 stride-1 convs: HIP Winograd F(4x4,3x3) transforms around hipBLASLt batched
+GEMMs; 1x1 convs: hipBLASLt GEMMs with fused BN / residual / ReLU epilogues; the rest: MIOpen)
+-> HIP row-max / top-k / gather+decode / batched NMS / final top-100 on the channels-last head
+outputs -> (N>1) one RCCL all-gather of the per-image detections.
 Weights are random-init (no checkpoints offline), data synthetic; images are
 sharded data-parallel (weak scaling: 8 images per GPU per step).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline     -- the dominant hand-written kernel (k_rowmax, HBM bound): algorithmic bytes
-                  per launch / average launch duration, timed with HIP events on the launch
-                  stream inside the timed steps;
+  roofline     -- the row-max kernel over the head logits (SURVEY 8d's unit; k_rowmax_nhwc for
+                  this channels-last network, HBM bound): algorithmic bytes per launch / average
+                  launch duration, timed with HIP events on the launch stream inside the timed
+                  steps;
   cpu_baseline -- the same workload on the host cores (rank 0, N=1 only): PyTorch-CPU
                   convolutions + the C oracle (oracle/, a port of the reference CPU path) on a
                   bounded sample.
