@@ -47,8 +47,48 @@ def wrap_ddp(model, device_ids=None):
     return DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False)
 
 
-def train_step(model, optimizer, img, img_meta, gt_bboxes, gt_labels, grad_clip=None):
+def allreduce_grads(model, coalesce=True, bucket_size_mb=-1):
+    """`allreduce_grads` of the reference (mmdet/core/utils/dist_utils.py:9-43) for callers that
+    drive the optimizer themselves instead of wrapping the model in DDP: average the gradients
+    of all trainable parameters over the ranks.  coalesce: one flat buffer per dtype (or per
+    bucket of bucket_size_mb) -> one all-reduce each on RCCL, divided by the world size, copied
+    back -- ~151 MB fp32 for R-50, a single large ring/tree collective per step."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size()
+    if world == 1:
+        return
+    grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
+    if not coalesce:
+        for g in grads:
+            dist.all_reduce(g.div_(world))
+        return
+    buckets = OrderedDict()
+    limit = bucket_size_mb * 1024 * 1024 if bucket_size_mb > 0 else None
+    for g in grads:
+        key = g.type()
+        lst = buckets.setdefault(key, [[]])
+        if limit is not None and sum(t.numel() * t.element_size() for t in lst[-1]) >= limit:
+            lst.append([])
+        lst[-1].append(g)
+    for lst in buckets.values():
+        for bucket in lst:
+            if not bucket:
+                continue
+            flat = torch.cat([t.reshape(-1) for t in bucket])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            off = 0
+            for t in bucket:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+
+
+def train_step(model, optimizer, img, img_meta, gt_bboxes, gt_labels, grad_clip=None,
+               allreduce=False):
     """One iteration.  grad_clip: dict(max_norm=35, norm_type=2) like optimizer_config.grad_clip.
+    allreduce=True averages the gradients with `allreduce_grads` (a model NOT wrapped in DDP).
     Returns the log_vars of parse_losses as python floats (one host sync at the end)."""
     losses = model(img, img_meta, return_loss=True, gt_bboxes=gt_bboxes, gt_labels=gt_labels)
     if losses is None:                       # an image without valid anchors (reference :362-363)
@@ -56,6 +96,8 @@ def train_step(model, optimizer, img, img_meta, gt_bboxes, gt_labels, grad_clip=
     loss, log_vars = parse_losses(losses)
     optimizer.zero_grad()
     loss.backward()
+    if allreduce:                            # DistOptimizerHook.after_train_iter (dist_utils.py:46-57)
+        allreduce_grads(model)
     if grad_clip is not None:
         clip_grad_norm_([p for p in model.parameters() if p.requires_grad and p.grad is not None],
                         **grad_clip)
