@@ -121,9 +121,10 @@ class Stepper(object):
             idx = ops.select_topk(geom, rm)
             boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors,
                                                       True)
-            dets, labels, rows, num = ops.multiclass_nms(boxes, scores_t, geom.R,
-                                                         self.cfg.score_thr, self.cfg.nms.iou_thr,
-                                                         self.cfg.max_per_img, best_score=best)[:4]
+            dets, labels, rows, num = ops.multiclass_nms_lazy(boxes, scores_t, geom.R,
+                                                              self.cfg.score_thr,
+                                                              self.cfg.nms.iou_thr,
+                                                              self.cfg.max_per_img, best_score=best)
         else:
             dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
                                                      self.cfg.score_thr, self.cfg.nms.iou_thr,

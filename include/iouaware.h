@@ -141,6 +141,28 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
                   float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
                   float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream);
 
+/* The same result (dets / labels / rows / num) with the NMS evaluated lazily: the (class, box)
+ * pairs of an image are walked in the final order (score desc, class asc, row asc) and a pair
+ * is kept iff no already kept pair of its class suppresses it; max_per_img survivors end the
+ * walk -- greedy per-class NMS decides a box from higher-ranked boxes only, so these are exactly
+ * the detections multiclass_nms returns (bbox_nms.py:33-56), without resolving 80 complete class
+ * problems.  candidates: pairs walked per image at most (0 = default 2048); an image that runs
+ * out of them with fewer than max_per_img survivors takes the complete path.  The per-class
+ * keep lists in the workspace are NOT produced by this entry point.                        */
+int ia_get_bboxes_lazy(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                       const float *img_hw, const float *scale_factor, int rescale,
+                       float score_thr, float iou_thr, int max_per_img, int candidates,
+                       void *workspace, size_t workspace_bytes, float *dets, int32_t *labels,
+                       int32_t *rows, int32_t *num, void *stream);
+
+/* The NMS stage of ia_get_bboxes_lazy on its own (inputs as ia_multiclass_nms).             */
+size_t ia_multiclass_nms_lazy_workspace_bytes(int batch, int R, int C);
+int ia_multiclass_nms_lazy(const float *boxes, const float *scores_t, const float *best_score,
+                           int batch, int R, int C, float score_thr, float iou_thr,
+                           int max_per_img, int candidates, void *workspace,
+                           size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
+                           int32_t *num, void *stream);
+
 /* Workspace carve-up of ia_get_bboxes (host helper for stage-level tests):
  * byte offsets of rowmax, cand_idx, boxes, scores_t, keep_count, keep_rows,
  * best_score, NMS stage workspace (bit matrix, sorted rows, counts).          */

@@ -14,7 +14,7 @@ static void base_from_geom(const ia_head_geom *g, BaseAnchors &ba)
     memcpy(ba.v, g->base_anchors, sizeof(ba.v));
 }
 
-struct WsLayout { size_t off[9]; size_t total; int32_t N, R, Rs; };
+struct WsLayout { size_t off[11]; size_t total; int32_t N, R, Rs; };
 
 static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
 {
@@ -39,6 +39,8 @@ static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
     w.off[7] = o; o = align_up(o + nms_workspace_bytes(batch, w.R, t.C, noff), 256);   // NMS stage
     o = align_up(o + finalize_workspace_bytes(batch, w.Rs, t.C), 256);                 // + final keys
     w.off[8] = o; o = align_up(o + select_workspace_bytes(t, batch), 256);             // top-k parts
+    w.off[9] = o; o = align_up(o + lazy_workspace_bytes(batch, w.Rs, t.C), 256);       // lazy NMS
+    w.off[10] = o; o = align_up(o + B * sizeof(int32_t), 256);                         // need_full
     w.total = o;
     return 0;
 }
@@ -155,6 +157,52 @@ int ia_multiclass_nms(const float *boxes, const float *scores_t, const float *be
                                max_per_img, fin_ws, dets, labels, rows, num, (hipStream_t)stream);
 }
 
+// stage-level lazy NMS: lazy walk first, the complete path (gated) for the images it cannot finish
+size_t ia_multiclass_nms_lazy_workspace_bytes(int batch, int R, int C)
+{
+    const size_t full = ia_multiclass_nms_workspace_bytes(batch, R, C);
+    if (full == 0) return 0;
+    const int Rs = (R + 63) / 64 * 64;
+    return ia::align_up(full, 256) + ia::align_up(ia::lazy_workspace_bytes(batch, Rs, C), 256) +
+           ia::align_up((size_t)batch * sizeof(int32_t), 256) +                      // need_full
+           ia::align_up((size_t)batch * C * sizeof(int32_t), 256) +                  // keep_count
+           ia::align_up((size_t)batch * C * Rs * sizeof(int32_t), 256);              // keep_rows
+}
+
+int ia_multiclass_nms_lazy(const float *boxes, const float *scores_t, const float *best_score,
+                           int batch, int R, int C, float score_thr, float iou_thr,
+                           int max_per_img, int candidates, void *workspace,
+                           size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
+                           int32_t *num, void *stream)
+{
+    const int Rs = (R + 63) / 64 * 64;
+    if (!workspace || candidates < 0) return IA_E_ARG;
+    const size_t need = ia_multiclass_nms_lazy_workspace_bytes(batch, R, C);
+    if (need == 0 || workspace_bytes < need) return IA_E_WORKSPACE;
+    char *ws = static_cast<char *>(workspace);
+    void *full_ws = ws;
+    ws += ia::align_up(ia_multiclass_nms_workspace_bytes(batch, R, C), 256);
+    void *lazy_ws = ws;
+    ws += ia::align_up(ia::lazy_workspace_bytes(batch, Rs, C), 256);
+    int32_t *need_full = reinterpret_cast<int32_t *>(ws);
+    ws += ia::align_up((size_t)batch * sizeof(int32_t), 256);
+    int32_t *kc = reinterpret_cast<int32_t *>(ws);
+    ws += ia::align_up((size_t)batch * C * sizeof(int32_t), 256);
+    int32_t *kr = reinterpret_cast<int32_t *>(ws);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ia::launch_lazy_nms(boxes, scores_t, batch, R, Rs, C, score_thr, iou_thr, max_per_img,
+                                 candidates, lazy_ws, dets, labels, rows, num, need_full, s);
+    if (rc) return rc;
+    if ((rc = ia::launch_nms(boxes, scores_t, best_score, batch, R, Rs, C, score_thr, iou_thr,
+                             full_ws, kc, kr, s, need_full)))
+        return rc;
+    size_t off[3];
+    char *fin_ws = static_cast<char *>(full_ws) +
+                   (ia::nms_workspace_bytes(batch, R, C, off) + 255) / 256 * 256;
+    return ia::launch_finalize(boxes, scores_t, kc, kr, batch, R, Rs, C, max_per_img, fin_ws, dets,
+                               labels, rows, num, s, need_full);
+}
+
 size_t ia_multiclass_soft_nms_workspace_bytes(int batch, int R, int C)
 {
     if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1) return 0;
@@ -207,10 +255,14 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
     return 0;
 }
 
-int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
-                  const float *img_hw, const float *scale_factor, int rescale, float score_thr,
-                  float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
-                  float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream)
+// lazy_candidates < 0: the complete NMS for every image (keep_count / keep_rows of all classes
+// are produced); >= 0: lazy NMS first (0 = default candidate count), complete path only for the
+// images it could not finish
+static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                           const float *img_hw, const float *scale_factor, int rescale,
+                           float score_thr, float iou_thr, int max_per_img, int lazy_candidates,
+                           void *workspace, size_t workspace_bytes, float *dets, int32_t *labels,
+                           int32_t *rows, int32_t *num, void *stream)
 {
     ia::WsLayout w;
     int rc = ia::ws_layout(g, batch, w);
@@ -237,14 +289,45 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
     if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
                                 scale_factor, rescale, boxes, scores_t, best, w.Rs, s)))
         return rc;
+    const int32_t *gate = nullptr;
+    if (lazy_candidates >= 0) {
+        int32_t *need_full = reinterpret_cast<int32_t *>(ws + w.off[10]);
+        if ((rc = ia::launch_lazy_nms(boxes, scores_t, batch, w.R, w.Rs, t.C, score_thr, iou_thr,
+                                      max_per_img, lazy_candidates, ws + w.off[9], dets, labels,
+                                      rows, num, need_full, s)))
+            return rc;
+        gate = need_full;
+    }
     if ((rc = ia::launch_nms(boxes, scores_t, best, batch, w.R, w.Rs, t.C, score_thr, iou_thr,
-                             nms_ws, kc, kr, s)))
+                             nms_ws, kc, kr, s, gate)))
         return rc;
     size_t noff[3];
     char *fin_ws = static_cast<char *>(nms_ws) +
                    (ia::nms_workspace_bytes(batch, w.R, t.C, noff) + 255) / 256 * 256;
     return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, fin_ws,
-                               dets, labels, rows, num, s);
+                               dets, labels, rows, num, s, gate);
+}
+
+int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                  const float *img_hw, const float *scale_factor, int rescale, float score_thr,
+                  float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
+                  float *dets, int32_t *labels, int32_t *rows, int32_t *num, void *stream)
+{
+    return get_bboxes_impl(g, p, batch, dtype, img_hw, scale_factor, rescale, score_thr, iou_thr,
+                           max_per_img, -1, workspace, workspace_bytes, dets, labels, rows, num,
+                           stream);
+}
+
+int ia_get_bboxes_lazy(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                       const float *img_hw, const float *scale_factor, int rescale,
+                       float score_thr, float iou_thr, int max_per_img, int candidates,
+                       void *workspace, size_t workspace_bytes, float *dets, int32_t *labels,
+                       int32_t *rows, int32_t *num, void *stream)
+{
+    if (candidates < 0) return IA_E_ARG;
+    return get_bboxes_impl(g, p, batch, dtype, img_hw, scale_factor, rescale, score_thr, iou_thr,
+                           max_per_img, candidates, workspace, workspace_bytes, dets, labels, rows,
+                           num, stream);
 }
 
 size_t ia_nms_workspace_bytes(int n) { return ia::nms_single_workspace_bytes(n); }

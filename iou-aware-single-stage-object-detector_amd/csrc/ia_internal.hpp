@@ -57,12 +57,19 @@ int nms_adj_words(int R);            // 64-bit words per adjacency row (padded)
 size_t nms_workspace_bytes(int batch, int R, int C, size_t off[3]);
 int launch_nms(const float *boxes, const float *scores_t, const float *best_score, int batch,
                int R, int Rs, int C, float score_thr, float iou_thr, void *workspace,
-               int32_t *keep_count, int32_t *keep_rows, hipStream_t s);
+               int32_t *keep_count, int32_t *keep_rows, hipStream_t s,
+               const int32_t *gate = nullptr);       // gate (B): images with gate[b] == 0 are skipped
 size_t finalize_workspace_bytes(int batch, int Rs, int C);
 int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
                     const int32_t *keep_rows, int batch, int R, int Rs, int C, int max_per_img,
                     void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
-                    hipStream_t s);
+                    hipStream_t s, const int32_t *gate = nullptr);
+// lazy NMS (lazynms.hip): the detections straight from the globally best (class, box) pairs
+size_t lazy_workspace_bytes(int batch, int Rs, int C);
+int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R, int Rs, int C,
+                    float score_thr, float iou_thr, int max_per_img, int candidates,
+                    void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
+                    int32_t *need_full, hipStream_t s);
 size_t nms_single_workspace_bytes(int n);
 int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
                       void *workspace, size_t workspace_bytes, hipStream_t s);

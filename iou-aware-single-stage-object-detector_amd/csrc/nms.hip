@@ -37,55 +37,13 @@
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 #include "ia_block.hpp"
+#include "ia_nms.hpp"
 
 namespace ia {
 
 constexpr int kResThreads = 256;              // k_nms_resolve workgroup
 constexpr int kResWaves = kResThreads / kWave;
 constexpr int kAdjGroup = 16;                 // adjacency row words are padded to a multiple of this
-
-struct IouThr {
-    double mid;      // midpoint between thr and its fp32 predecessor
-    float thr;
-    int32_t inclusive;
-    int32_t is_half; // thr == 0.5f: fl(inter/uni) >= 0.5  <=>  2*inter >= uni, exact in fp32
-};
-
-static IouThr make_thr(float thr)
-{
-    IouThr t;
-    t.thr = thr;
-    float pred = nextafterf(thr, -INFINITY);
-    t.mid = ((double)pred + (double)thr) * 0.5;
-    uint32_t bits = __builtin_bit_cast(uint32_t, thr);
-    t.inclusive = (bits & 1u) == 0u;
-    t.is_half = (thr == 0.5f);
-    return t;
-}
-
-// suppressor box s (earlier in the order, "i" of nms_cpu.cpp:37-55) vs candidate c ("j")
-__device__ __forceinline__ bool suppresses(float sx1, float sy1, float sx2, float sy2, float sarea,
-                                           float cx1, float cy1, float cx2, float cy2, float carea,
-                                           const IouThr &t)
-{
-    float xx1 = (sx1 < cx1) ? cx1 : sx1;
-    float yy1 = (sy1 < cy1) ? cy1 : sy1;
-    float xx2 = (cx2 < sx2) ? cx2 : sx2;
-    float yy2 = (cy2 < sy2) ? cy2 : sy2;
-    float w = (xx2 - xx1) + 1.0f;  w = (0.0f < w) ? w : 0.0f;
-    float h = (yy2 - yy1) + 1.0f;  h = (0.0f < h) ? h : 0.0f;
-    float inter = w * h;
-    float uni = (sarea + carea) - inter;
-    if (uni > 0.0f) {
-        // thr = 0.5 (every reference config): q = inter/uni rounds to >= 0.5 iff q >= 0.5 - 2^-26,
-        // and no two fp32 numbers 2*inter < uni are closer than 2^-24 * uni, so the test is the
-        // exact fp32 comparison 2*inter >= uni (2*inter is exact).
-        if (t.is_half) return (inter + inter) >= uni;
-        double lhs = (double)inter, rhs = t.mid * (double)uni;
-        return t.inclusive ? (lhs >= rhs) : (lhs > rhs);
-    }
-    return (inter / uni) >= t.thr;
-}
 
 // value of lane `src` (wave-uniform index) in every lane: v_readlane_b32, no LDS round trip
 __device__ __forceinline__ float bcast(float v, int src)
@@ -103,12 +61,14 @@ struct AdjArgs {
     IouThr thr;
     float score_thr;
     int32_t R, W, stride;
+    const int32_t *gate;         // optional (B): images with gate[b] == 0 are skipped
 };
 
 __global__ void __launch_bounds__(64) k_adj(AdjArgs a)
 {
     const int lane = threadIdx.x;
     const int tj = blockIdx.x, ti = blockIdx.y, b = blockIdx.z;
+    if (a.gate && !a.gate[b]) return;
     const int r = ti * 64 + lane, c = tj * 64 + lane;
     const float *bx = a.boxes + (size_t)b * a.R * a.stride;
     const float *bs = a.best_score ? a.best_score + (size_t)b * a.R : nullptr;
@@ -135,9 +95,11 @@ __global__ void __launch_bounds__(64) k_adj(AdjArgs a)
 }
 
 static int launch_adj(const float *boxes, int stride, const float *best_score, int batch, int R,
-                      int W, const IouThr &thr, float score_thr, uint64_t *adj, hipStream_t s)
+                      int W, const IouThr &thr, float score_thr, uint64_t *adj, hipStream_t s,
+                      const int32_t *gate = nullptr)
 {
     AdjArgs a;
+    a.gate = gate;
     a.boxes = boxes; a.best_score = best_score; a.adj = adj; a.thr = thr; a.score_thr = score_thr;
     a.R = R; a.W = W; a.stride = stride;
     const unsigned tiles = (unsigned)((R + 63) / 64);
@@ -203,12 +165,14 @@ struct SortArgs {
     int32_t *n_in;
     float score_thr;
     int32_t R, Rs, C;
+    const int32_t *gate;
 };
 
 __global__ void __launch_bounds__(kSortThreads) k_class_sort(SortArgs a)
 {
     extern __shared__ uint64_t keys[];
     const int c = blockIdx.x, b = blockIdx.y;
+    if (a.gate && !a.gate[b]) return;
     const size_t prob = (size_t)b * a.C + c;
     ClassSrc src{a.scores_t + prob * a.Rs, a.score_thr};
     class_sort_block((uint32_t)a.R, src, a.sorted_rows + prob * a.Rs, a.n_in + prob, keys);
@@ -340,13 +304,14 @@ struct NmsArgs {
     int32_t *keep_count;
     int32_t *keep_rows;
     int32_t R, Rs, C, W, B, Bpad;
+    const int32_t *gate;
 };
 
 __global__ void __launch_bounds__(kResThreads) k_nms_resolve(NmsArgs a)
 {
     __shared__ ResSmem sm;
     const int c = blockIdx.x / a.Bpad, b = blockIdx.x - c * a.Bpad;   // XCD = blockIdx % 8 = b % 8
-    if (b >= a.B) return;
+    if (b >= a.B || (a.gate && !a.gate[b])) return;
     const size_t prob = (size_t)b * a.C + c;
     uint32_t cnt = nms_resolve_block((uint32_t)a.R, (uint32_t)a.W, (uint32_t)a.n_in[prob],
                                      a.sorted_rows + prob * a.Rs, a.adj + (size_t)b * a.R * a.W,
@@ -376,7 +341,7 @@ size_t nms_workspace_bytes(int batch, int R, int C, size_t off[3])
 
 int launch_nms(const float *boxes, const float *scores_t, const float *best_score, int batch,
                int R, int Rs, int C, float score_thr, float iou_thr, void *workspace,
-               int32_t *keep_count, int32_t *keep_rows, hipStream_t s)
+               int32_t *keep_count, int32_t *keep_rows, hipStream_t s, const int32_t *gate)
 {
     if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1 || Rs < R) return IA_E_ARG;
     if (!boxes || !scores_t || !workspace || !keep_count || !keep_rows) return IA_E_ARG;
@@ -387,9 +352,10 @@ int launch_nms(const float *boxes, const float *scores_t, const float *best_scor
     uint16_t *sorted_rows = reinterpret_cast<uint16_t *>(ws + off[1]);
     int32_t *n_in = reinterpret_cast<int32_t *>(ws + off[2]);
     const int W = nms_adj_words(R);
-    int rc = launch_adj(boxes, 4, best_score, batch, R, W, make_thr(iou_thr), score_thr, adj, s);
+    int rc = launch_adj(boxes, 4, best_score, batch, R, W, make_thr(iou_thr), score_thr, adj, s, gate);
     if (rc) return rc;
     SortArgs sa;
+    sa.gate = gate;
     sa.scores_t = scores_t; sa.sorted_rows = sorted_rows; sa.n_in = n_in; sa.score_thr = score_thr;
     sa.R = R; sa.Rs = Rs; sa.C = C;
     size_t lds = sizeof(uint64_t) * (size_t)pow2_at_least((uint32_t)R);
@@ -399,6 +365,7 @@ int launch_nms(const float *boxes, const float *scores_t, const float *best_scor
     hipLaunchKernelGGL(k_class_sort, dim3((unsigned)C, (unsigned)batch), dim3(kSortThreads), lds, s, sa);
     if ((rc = hip_status(hipGetLastError()))) return rc;
     NmsArgs a;
+    a.gate = gate;
     a.sorted_rows = sorted_rows; a.n_in = n_in; a.adj = adj; a.keep_count = keep_count;
     a.keep_rows = keep_rows; a.R = R; a.Rs = Rs; a.C = C; a.W = W; a.B = batch;
     a.Bpad = (batch + 7) / 8 * 8;
@@ -475,12 +442,14 @@ struct FinalKeyArgs {
     const int32_t *keep_rows;
     uint64_t *flat;          // (B, C*Rs)
     int32_t Rs, C;
+    const int32_t *gate;
 };
 
 __global__ void __launch_bounds__(256) k_final_keys(FinalKeyArgs a)
 {
     __shared__ uint32_t s_prefix;
     const int c = blockIdx.x, b = blockIdx.y;
+    if (a.gate && !a.gate[b]) return;
     const int32_t *kc = a.keep_count + (size_t)b * a.C;
     if (threadIdx.x < kWave) {
         uint32_t part = 0;
@@ -512,6 +481,7 @@ struct FinalArgs {
     int32_t *rows;
     int32_t *num;
     int32_t R, Rs, C, max_per_img;
+    const int32_t *gate;
 };
 
 constexpr int kFinalThreads = 1024;
@@ -526,6 +496,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize_part(FinalArgs a)
     __shared__ uint32_t s_total;
     const int part = blockIdx.x, b = blockIdx.y;
     const uint32_t tid = threadIdx.x;
+    if (a.gate && !a.gate[b]) return;
     if (tid < kWave) {
         uint32_t s = 0;
         for (int c = tid; c < a.C; c += kWave) s += (uint32_t)a.keep_count[(size_t)b * a.C + c];
@@ -556,6 +527,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_finalize(FinalArgs a)
     __shared__ uint32_t prefix[kFinalMaxC + 1];
     const int b = blockIdx.x;
     const uint32_t tid = threadIdx.x;
+    if (a.gate && !a.gate[b]) return;
     const int C = a.C;
     const int32_t *kc = a.keep_count + (size_t)b * C;
     if (tid == 0) {
@@ -618,18 +590,20 @@ size_t finalize_workspace_bytes(int batch, int Rs, int C)
 int launch_finalize(const float *boxes, const float *scores_t, const int32_t *keep_count,
                     const int32_t *keep_rows, int batch, int R, int Rs, int C, int max_per_img,
                     void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
-                    hipStream_t s)
+                    hipStream_t s, const int32_t *gate)
 {
     if (batch < 1 || C < 1 || C > kFinalMaxC || max_per_img < 1 || max_per_img > IA_MAX_PER_IMG)
         return IA_E_ARG;
     if (!dets || !labels || !rows || !num || !workspace) return IA_E_ARG;
     FinalKeyArgs k;
+    k.gate = gate;
     k.scores_t = scores_t; k.keep_count = keep_count; k.keep_rows = keep_rows;
     k.flat = static_cast<uint64_t *>(workspace); k.Rs = Rs; k.C = C;
     hipLaunchKernelGGL(k_final_keys, dim3((unsigned)C, (unsigned)batch), dim3(256), 0, s, k);
     int rc = hip_status(hipGetLastError());
     if (rc) return rc;
     FinalArgs a;
+    a.gate = gate;
     a.boxes = boxes; a.scores_t = scores_t; a.keep_count = keep_count; a.keep_rows = keep_rows;
     a.flat = k.flat; a.dets = dets; a.labels = labels; a.rows = rows; a.num = num;
     a.R = R; a.Rs = Rs; a.C = C; a.max_per_img = max_per_img;

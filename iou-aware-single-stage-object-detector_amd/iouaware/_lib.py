@@ -70,6 +70,11 @@ SIGNATURES = {
     'ia_get_bboxes_workspace_bytes': (_sz, [_G, _i]),
     'ia_get_bboxes': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _f, _f, _i, _vp, _sz, _vp, _vp, _vp,
                            _vp, _vp]),
+    'ia_multiclass_nms_lazy_workspace_bytes': (_sz, [_i, _i, _i]),
+    'ia_multiclass_nms_lazy': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _sz, _vp, _vp, _vp,
+                                    _vp, _vp]),
+    'ia_get_bboxes_lazy': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _f, _f, _i, _i, _vp, _sz, _vp, _vp, _vp,
+                                _vp, _vp]),
     'ia_get_bboxes_workspace_layout': (_i, [_G, _i, C.POINTER(_sz * 8)]),
     'ia_nms_workspace_bytes': (_sz, [_i]),
     'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -166,11 +166,14 @@ def _meta_tensors(img_shapes, scale_factors, device):
 
 
 def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr, iou_thr,
-               max_per_img, debug=False, soft=None):
+               max_per_img, debug=False, soft=None, lazy=True, lazy_candidates=0):
     """Whole post-conv inference path for a batch.
 
     soft: None for hard NMS (one C-ABI call), or dict(method=, sigma=, min_score=) for
     test_cfg.nms.type='soft_nms' (the stage calls with ia_multiclass_soft_nms at the end).
+    lazy: evaluate the NMS lazily (ia_get_bboxes_lazy: same detections, the class problems are
+    not resolved completely); debug=True always takes the complete path, whose per-class keep
+    lists are part of the debug views.
 
     Returns device tensors dets (B,max_per_img,5) f32, labels (B,max_per_img) i32,
     rows (B,max_per_img) i32 (candidate row ids), num (B) i32.  With debug=True
@@ -200,9 +203,15 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
     rows = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
     num = torch.empty((B,), dtype=torch.int32, device=dev)
-    rc = L.ia_get_bboxes(geom.ref(), C.byref(p), B, dt, _ptr(hw), _ptr(sf), int(bool(rescale)),
-                         float(score_thr), float(iou_thr), int(max_per_img), _ptr(ws), nbytes,
-                         _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _stream())
+    if lazy and not debug:
+        rc = L.ia_get_bboxes_lazy(geom.ref(), C.byref(p), B, dt, _ptr(hw), _ptr(sf),
+                                  int(bool(rescale)), float(score_thr), float(iou_thr),
+                                  int(max_per_img), int(lazy_candidates), _ptr(ws), nbytes,
+                                  _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _stream())
+    else:
+        rc = L.ia_get_bboxes(geom.ref(), C.byref(p), B, dt, _ptr(hw), _ptr(sf), int(bool(rescale)),
+                             float(score_thr), float(iou_thr), int(max_per_img), _ptr(ws), nbytes,
+                             _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _stream())
     _lib.check(rc, 'ia_get_bboxes')
     if not debug:
         return dets, labels, rows, num
@@ -284,6 +293,25 @@ def multiclass_nms(boxes, scores_t, R, score_thr, iou_thr, max_per_img, best_sco
                                             _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num),
                                             _ptr(kc), _ptr(kr), _stream()), 'ia_multiclass_nms')
     return dets, labels, rows, num, kc, kr
+
+
+def multiclass_nms_lazy(boxes, scores_t, R, score_thr, iou_thr, max_per_img, best_score=None,
+                        candidates=0):
+    """the NMS stage evaluated lazily (csrc/lazynms.hip): -> dets, labels, rows, num"""
+    _require_gpu(boxes, 'boxes')
+    B, Cn, Rs = scores_t.shape
+    dev = boxes.device
+    dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    rows = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().ia_multiclass_nms_lazy_workspace_bytes(B, int(R), Cn)
+    ws = _workspace(dev, nbytes)
+    _lib.check(_lib.lib().ia_multiclass_nms_lazy(
+        _ptr(boxes.contiguous()), _ptr(scores_t.contiguous()), _ptr(best_score), B, int(R), Cn,
+        float(score_thr), float(iou_thr), int(max_per_img), int(candidates), _ptr(ws), nbytes,
+        _ptr(dets), _ptr(labels), _ptr(rows), _ptr(num), _stream()), 'ia_multiclass_nms_lazy')
+    return dets, labels, rows, num
 
 
 SOFT_METHODS = {'linear': 1, 'gaussian': 2}

@@ -81,6 +81,13 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
     dets, labels, rows, num, dbg = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale,
                                                   score_thr, iou_thr, max_per_img, debug=True)
     torch.cuda.synchronize()
+    # the lazy evaluation of the NMS (default product path) returns the very same tensors; with 128
+    # / 100 candidates most images run out of candidates and take the gated complete path
+    for cand in (0, 128, max_per_img):
+        lz = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale, score_thr, iou_thr, max_per_img,
+                            lazy=True, lazy_candidates=cand)
+        for name, x, y in zip(('dets', 'labels', 'rows', 'num'), lz, (dets, labels, rows, num)):
+            assert torch.equal(x, y), 'lazy (%d candidates) %s differs' % (cand, name)
     dets, labels, rows, num = dets.cpu().numpy(), labels.cpu().numpy(), rows.cpu().numpy(), \
         num.cpu().numpy()
     dbg = {k: v.cpu().numpy() for k, v in dbg.items()}
@@ -214,6 +221,11 @@ def _stage_chain(ops, geom, dc, dr, di, shapes, sfs):
     d0 = ops.multiclass_nms(boxes, scores_t, geom.R, 0.05, 0.5, 100)      # without the activity filter
     for a, b in zip(d0[:5], d1[:5]):          # dets, labels, rows, num, keep_count
         assert torch.equal(a, b)
+    for cand in (0, 100):
+        d3 = ops.multiclass_nms_lazy(boxes, scores_t, geom.R, 0.05, 0.5, 100, best_score=best,
+                                     candidates=cand)
+        for a, b in zip(d1[:4], d3):
+            assert torch.equal(a, b)
     d2 = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, True, 0.05, 0.5, 100)
     torch.cuda.synchronize()
     for a, b in zip(d1[:4], d2):
