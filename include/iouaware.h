@@ -364,6 +364,11 @@ int ia_nhwc_to_nchw(const void *src, void *dst, int dtype, int N, int C, int64_t
 int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int B, int H,
                                 int W, int C, float *out, void *stream);
 
+/* FPN top-down step, in place (mmdet/models/necks/fpn.py:118-120): fine += nearest-x2(coarse);
+ * channels-last fp32, H = 2*Hc, W = 2*Wc, C % 4 == 0.                                          */
+int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W, int Hc, int Wc,
+                           int C, void *stream);
+
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the
  * device implementation bit-for-bit: op 0 exp, 1 log, 2 sigmoid, 3 sqrt,

@@ -408,3 +408,58 @@ extern "C" int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, c
                        (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------
+// FPN top-down step (reference mmdet/models/necks/fpn.py:118-120):
+//   laterals[i-1] += F.interpolate(laterals[i], scale_factor=2, mode='nearest')
+// in place on channels-last tensors: one read of the coarse map (L2-resident: every coarse pixel
+// serves four fine pixels), one read-modify-write of the fine map -- instead of materialising the
+// upsampled tensor and adding it in a second pass.
+namespace ia {
+
+struct UpAddArgs {
+    float *fine;                 // (B, H, W, C)
+    const float *coarse;         // (B, Hc, Wc, C)
+    int32_t B, H, W, Hc, Wc, C;
+};
+
+__global__ void __launch_bounds__(256) k_upsample_add(UpAddArgs a)
+{
+    const int c4n = a.C / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)a.B * a.H * a.W * c4n;
+    if (gid >= total) return;
+    const int c = (int)(gid % c4n) * 4;
+    int64_t p = gid / c4n;
+    const int x = (int)(p % a.W); p /= a.W;
+    const int y = (int)(p % a.H);
+    const int b = (int)(p / a.H);
+    // nearest: src = floor(dst * in / out); for the exact factor 2 this is dst >> 1, and in general
+    // PyTorch's scale_factor=2 path uses floor(dst * 0.5)
+    int ys = y >> 1, xs = x >> 1;
+    ys = (ys < a.Hc) ? ys : a.Hc - 1;
+    xs = (xs < a.Wc) ? xs : a.Wc - 1;
+    float4 *f = reinterpret_cast<float4 *>(a.fine + (((size_t)b * a.H + y) * a.W + x) * a.C + c);
+    const float4 u = *reinterpret_cast<const float4 *>(
+        a.coarse + (((size_t)b * a.Hc + ys) * a.Wc + xs) * a.C + c);
+    float4 v = *f;
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    *f = v;
+}
+
+}  // namespace ia
+
+extern "C" int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W, int Hc,
+                                      int Wc, int C, void *stream)
+{
+    if (!fine || !coarse || B < 1 || H < 1 || W < 1 || Hc < 1 || Wc < 1 || C < 4 || (C & 3))
+        return IA_E_ARG;
+    if (H != 2 * Hc || W != 2 * Wc) return IA_E_ARG;      // scale_factor = 2 exactly (fpn.py:119)
+    ia::UpAddArgs a;
+    a.fine = fine; a.coarse = coarse; a.B = B; a.H = H; a.W = W; a.Hc = Hc; a.Wc = Wc; a.C = C;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 2147483647LL) return IA_E_ARG;
+    hipLaunchKernelGGL(ia::k_upsample_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}

@@ -138,6 +138,35 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     return ops.channel_affine_act_(_conv_nobias(self.conv, x), None, f['bias'], relu=relu)
 
 
+def _fpn_forward(self, inputs):
+    """FPN.forward with the top-down `lat[i-1] + interpolate(lat[i])` as one in-place kernel"""
+    import torch.nn.functional as F_
+    lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+    n = len(lat)
+    ok = (not self.training) and (not torch.is_grad_enabled()) and all(
+        t.is_cuda and t.dtype == torch.float32 and t.shape[1] % 4 == 0
+        and t.is_contiguous(memory_format=torch.channels_last) for t in lat)
+    if not ok or len(inputs) != len(self.in_channels):
+        return type(self).forward(self, inputs)
+    for i in range(n - 1, 0, -1):
+        if lat[i - 1].shape[2] == 2 * lat[i].shape[2] and lat[i - 1].shape[3] == 2 * lat[i].shape[3]:
+            ops.upsample2x_add_(lat[i - 1], lat[i])
+        else:
+            lat[i - 1] = lat[i - 1] + F_.interpolate(lat[i], scale_factor=2, mode='nearest')
+    outs = [self.fpn_convs[i](lat[i]) for i in range(n)]
+    if self.num_outs > n:
+        if not self.add_extra_convs:
+            for _ in range(self.num_outs - n):
+                outs.append(F_.max_pool2d(outs[-1], 1, stride=2))
+        else:
+            first = inputs[self.backbone_end_level - 1] if self.extra_convs_on_inputs else outs[-1]
+            outs.append(self.fpn_convs[n](first))
+            for i in range(n + 1, self.num_outs):
+                src = F_.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
+                outs.append(self.fpn_convs[i](src))
+    return tuple(outs)
+
+
 def _head_forward(self, feats):
     w = self._ia_wino
     if (not self.training) and w.usable(feats):
@@ -175,6 +204,11 @@ def fuse_inference(model, winograd=False):
             if type(m).__name__ == 'FPN':
                 fpn_convs.update(id(c) for c in m.fpn_convs)
     for m in model.modules():
+        if winograd and type(m).__name__ == 'FPN':
+            m._ia_wino = True                     # marker for unfuse_inference
+            m.forward = types.MethodType(_fpn_forward, m)
+            n += 1
+            continue
         if winograd and type(m).__name__ == 'IoUawareRetinaHead':
             from .winograd import WinogradHead
             m._ia_wino = WinogradHead(m)

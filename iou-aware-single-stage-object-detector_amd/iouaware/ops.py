@@ -415,6 +415,16 @@ def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None
     return x
 
 
+def upsample2x_add_(fine, coarse):
+    """fine += nearest-x2(coarse), in place, channels-last fp32 (FPN top-down step)"""
+    _require_gpu(fine, 'fine')
+    B, Cn, H, W = fine.shape
+    _lib.check(_lib.lib().ia_upsample2x_add_nhwc(_ptr(fine), _ptr(coarse), B, H, W,
+                                                 int(coarse.shape[2]), int(coarse.shape[3]), Cn,
+                                                 _stream()), 'ia_upsample2x_add_nhwc')
+    return fine
+
+
 def affine_relu_maxpool(x, scale, shift):
     """relu(x * scale + shift) followed by MaxPool2d(3, 2, 1) on a channels-last fp32 tensor"""
     _require_gpu(x, 'x')

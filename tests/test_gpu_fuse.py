@@ -123,3 +123,16 @@ def test_linear_bias_act_matches_conv():
         assert float((got.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
     got = ops.linear_bias_act(x, w_kn, None)
     assert float((got.double() - (ref - b.double().view(1, -1, 1, 1))).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_upsample2x_add_matches_torch():
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for (B, C_, Hc, Wc) in [(2, 256, 25, 42), (1, 8, 1, 1), (3, 64, 7, 5)]:
+        fine = torch.randn(B, C_, 2 * Hc, 2 * Wc, device='cuda', generator=g).contiguous(
+            memory_format=torch.channels_last)
+        coarse = torch.randn(B, C_, Hc, Wc, device='cuda', generator=g).contiguous(
+            memory_format=torch.channels_last)
+        want = fine + torch.nn.functional.interpolate(coarse, scale_factor=2, mode='nearest')
+        got = ops.upsample2x_add_(fine, coarse)
+        assert got.data_ptr() == fine.data_ptr() and torch.equal(got, want)
