@@ -240,12 +240,14 @@ class WinogradHead(object):
             acts = nxt
         # outputs
         v = input_transform(plan, acts, 2, plan.buf('v', (72, T, F)))
-        m_cls = batched_gemm(v[:36], self.u_cls, plan.buf('mc', (36, T, self.c_cls)))
-        m_ri = batched_gemm(v[36:], self.u_ri, plan.buf('mr', (36, T, self.n_ri_pad)))
         new = lambda c: [torch.empty((B, c, h, w), dtype=torch.float32, device=feats[0].device,  # noqa: E731
                                      memory_format=torch.channels_last) for (h, w) in sizes]
         cls, reg, iou = new(self.c_cls), new(self.c_reg), new(self.c_iou)
+        # the 548 MB class logits are written FIRST: the (MFMA-bound) reg / iou GEMM behind them
+        # gives their write-back time to drain before the row-max kernel streams them back in
+        m_cls = batched_gemm(v[:36], self.u_cls, plan.buf('mc', (36, T, self.c_cls)))
         output_transform(plan, m_cls, self.c_cls, 1, self.b_cls, False, [(0, self.c_cls, cls, 0)])
+        m_ri = batched_gemm(v[36:], self.u_ri, plan.buf('mr', (36, T, self.n_ri_pad)))
         output_transform(plan, m_ri, self.n_ri_pad, 1, self.b_ri, False,
                          [(0, self.c_reg, reg, 0), (self.c_reg, self.c_iou, iou, 0)])
         return cls, reg, iou
