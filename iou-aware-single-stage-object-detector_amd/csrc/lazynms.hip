@@ -7,7 +7,10 @@
 // the final selection takes the survivors in (score desc, class asc, row asc) order -- which
 // inside a class is exactly the NMS order.  So walking ALL (class, box) pairs of an image in
 // that one global order and keeping a pair iff no already kept pair of the same class suppresses
-// it yields the survivors in final order; after max_per_img survivors nothing further can matter.
+// it yields the survivors in final order; after max_per_img + 1 survivors nothing further can
+// matter (the extra one only proves that more than max_num boxes survive, i.e. that the reference
+// sorts by score, bbox_nms.py:52-56; with at most max_num survivors it keeps the concatenation
+// order, which the walk restores from the pair indices).
 // With random-init weights (every one of the 375 440 pairs passes score_thr) ~220 pairs are
 // touched per image instead of 4 693 per class x 80 classes.
 //
@@ -110,10 +113,12 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_part(LazyArgs a)
 }
 
 struct LazySmem {
-    float4 box[kLazyMax];             // boxes of the candidates, in order
-    float4 kbox[IA_MAX_PER_IMG];      // kept: box, area, class
-    float karea[IA_MAX_PER_IMG];
-    int32_t kcls[IA_MAX_PER_IMG];
+    float4 box[kLazyMax];                 // boxes of the candidates, in order
+    float4 kbox[IA_MAX_PER_IMG + 1];      // kept (one more than max_per_img, see below): box,
+    float karea[IA_MAX_PER_IMG + 1];      // area, class, pair index c*Rs + r, score
+    int32_t kcls[IA_MAX_PER_IMG + 1];
+    uint32_t kidx[IA_MAX_PER_IMG + 1];
+    float kscore[IA_MAX_PER_IMG + 1];
 };
 
 __global__ void __launch_bounds__(kLazyThreads) k_lazy_greedy(LazyArgs a)
@@ -150,14 +155,17 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_greedy(LazyArgs a)
     if (tid < kWave) {
         const int lane = tid;
         const uint32_t cap = (uint32_t)a.max_per_img;
+        // bbox_nms.py:52-56 sorts by score ONLY when more than max_num boxes survive; with at
+        // most max_num survivors the result keeps the concatenation order (class asc, row asc).
+        // So the walk goes on until survivor number cap + 1 proves that the reference sorts.
+        const uint32_t want = cap + 1;
         uint32_t nk = 0;
-        for (uint32_t i0 = 0; i0 < m && nk < cap; i0 += kWave) {
+        for (uint32_t i0 = 0; i0 < m && nk < want; i0 += kWave) {
             const uint32_t i = i0 + lane;
             const bool live = i < m;
             const uint64_t key = live ? sel[i] : 0ull;
             const uint32_t idx = 0xffffffffu - (uint32_t)key;
             const int cls = live ? (int)(idx / (uint32_t)a.Rs) : -1;
-            const int row = (int)(idx % (uint32_t)a.Rs);
             const float4 q = live ? sm.box[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             const float area = ((q.z - q.x) + 1.0f) * ((q.w - q.y) + 1.0f);      // nms_cpu.cpp:18
             // (A) against the pairs kept in earlier chunks
@@ -170,18 +178,15 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_greedy(LazyArgs a)
             }
             // (B) inside the chunk, in order: an unsuppressed lane is kept and suppresses later lanes
             uint64_t alive = __ballot(!sup);
-            while (alive && nk < cap) {
+            while (alive && nk < want) {
                 const int j = __builtin_ctzll(alive);
                 alive &= alive - 1;
                 const float jx1 = __shfl(q.x, j), jy1 = __shfl(q.y, j), jx2 = __shfl(q.z, j);
                 const float jy2 = __shfl(q.w, j), jar = __shfl(area, j);
                 const int jc = __shfl(cls, j);
                 if (lane == j) {
-                    sm.kbox[nk] = q; sm.karea[nk] = area; sm.kcls[nk] = cls;
-                    dets[5 * nk + 0] = q.x; dets[5 * nk + 1] = q.y; dets[5 * nk + 2] = q.z;
-                    dets[5 * nk + 3] = q.w;
-                    dets[5 * nk + 4] = ordered_key_inv((uint32_t)(key >> 32));
-                    labels[nk] = cls; rows[nk] = row;
+                    sm.kbox[nk] = q; sm.karea[nk] = area; sm.kcls[nk] = cls; sm.kidx[nk] = idx;
+                    sm.kscore[nk] = ordered_key_inv((uint32_t)(key >> 32));
                 }
                 ++nk;
                 const bool hit = lane > j && !sup && cls == jc &&
@@ -191,16 +196,33 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_greedy(LazyArgs a)
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const bool done = (nk >= cap) || (total <= M);       // all pairs seen, or the cap reached
+        const bool sorted = nk > cap;                        // more than max_num survive: score order
+        const bool all_seen = !sorted && total <= M;         // every pair was walked: that is all
+        const bool done = sorted || all_seen;
+        const uint32_t nout = sorted ? cap : nk;
         if (lane == 0) {
             a.need_full[b] = done ? 0 : 1;
-            if (done) a.num[b] = (int32_t)nk;
+            if (done) a.num[b] = (int32_t)nout;
         }
-        if (done)
-            for (uint32_t d = nk + lane; d < cap; d += kWave) {
+        if (done) {
+            for (uint32_t e = lane; e < nout; e += kWave) {
+                uint32_t pos = e;
+                if (!sorted) {                               // concatenation order = pair index order
+                    pos = 0;
+                    const uint32_t me = sm.kidx[e];
+                    for (uint32_t j = 0; j < nout; ++j) pos += (sm.kidx[j] < me) ? 1u : 0u;
+                }
+                const float4 q = sm.kbox[e];
+                dets[5 * pos + 0] = q.x; dets[5 * pos + 1] = q.y; dets[5 * pos + 2] = q.z;
+                dets[5 * pos + 3] = q.w; dets[5 * pos + 4] = sm.kscore[e];
+                labels[pos] = sm.kcls[e];
+                rows[pos] = (int32_t)(sm.kidx[e] % (uint32_t)a.Rs);
+            }
+            for (uint32_t d = nout + lane; d < cap; d += kWave) {
                 for (int q5 = 0; q5 < 5; ++q5) dets[5 * d + q5] = 0.0f;
                 labels[d] = -1; rows[d] = -1;
             }
+        }
     }
 }
 
@@ -226,7 +248,8 @@ int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R,
         return IA_E_ARG;
     if (candidates <= 0) candidates = kLazyMax;
     if (candidates > kLazyMax) candidates = kLazyMax;
-    if (candidates < max_per_img) candidates = max_per_img;   // at least one survivor per candidate
+    if (candidates <= max_per_img) candidates = max_per_img + 1;   // the walk needs cap + 1 survivors
+    if (candidates > kLazyMax) candidates = kLazyMax;
     LazyArgs a;
     char *ws = static_cast<char *>(workspace);
     a.flat = reinterpret_cast<uint64_t *>(ws);

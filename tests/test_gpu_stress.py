@@ -1,0 +1,59 @@
+"""GPU (MI355X): randomised cross-checks of the paths that have two implementations of the same
+contract -- lazy vs complete NMS (bit-equal tensors), Winograd vs direct convolution -- over many
+shapes / thresholds, including the fall-back and tie-heavy regimes."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_lazy_nms_equals_complete_nms_random(seed):
+    from iouaware import ops
+    rs = np.random.RandomState(100 + seed)
+    B, R, Cn = int(rs.randint(1, 5)), int(rs.choice([37, 300, 1000, 4693])), int(rs.choice([1, 3, 80]))
+    Rs = (R + 63) // 64 * 64
+    span = float(rs.choice([80, 400, 1500]))
+    xy = rs.uniform(0, span, (B, R, 2))
+    wh = rs.uniform(4, 120, (B, R, 2))
+    boxes = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+    scores = (rs.uniform(0, 1, (B, Cn, Rs)) ** rs.choice([1, 4, 12])).astype(np.float32)
+    if seed % 2:                                       # heavy ties
+        scores = (np.round(scores * 16) / 16).astype(np.float32)
+        boxes = (np.round(boxes / 8) * 8).astype(np.float32)
+    scores[:, :, R:] = 0
+    bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    for score_thr, iou_thr, cap in ((0.05, 0.5, 100), (0.3, 0.3, 17), (0.0, 0.7, 300), (0.9, 0.5, 100)):
+        full = ops.multiclass_nms(bt, st, R, score_thr, iou_thr, cap)[:4]
+        for cand in (0, cap, 5 * cap):
+            lz = ops.multiclass_nms_lazy(bt, st, R, score_thr, iou_thr, cap, candidates=cand)
+            for name, a, b in zip(('dets', 'labels', 'rows', 'num'), full, lz):
+                assert torch.equal(a, b), (seed, score_thr, iou_thr, cap, cand, name)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_winograd_conv_random_shapes(seed):
+    from iouaware.winograd import WinogradConv3x3
+    rs = np.random.RandomState(seed)
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    for _ in range(4):
+        B, cin, cout = int(rs.randint(1, 4)), int(rs.choice([4, 12, 64, 260])), int(rs.choice([4, 36, 48, 256]))
+        h, w = int(rs.randint(1, 40)), int(rs.randint(1, 40))
+        x = torch.randn(B, cin, h, w, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, device='cuda', generator=g)
+        conv = WinogradConv3x3(wt, b, relu=bool(rs.randint(0, 2)))
+        pre = None
+        ref_in = x.double()
+        if rs.randint(0, 2):
+            s, t = torch.randn(cin, device='cuda', generator=g), torch.randn(cin, device='cuda', generator=g)
+            pre = (s, t, True)
+            ref_in = torch.relu(ref_in * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1))
+        y = conv(x, pre=pre)
+        ref = torch.nn.functional.conv2d(ref_in, wt.double(), b.double(), padding=1)
+        ref = ref.clamp(min=0) if conv.relu else ref
+        assert float((y.double() - ref).abs().max()) <= 3e-5 * max(float(ref.abs().max()), 1.0), (B, cin, cout, h, w)
