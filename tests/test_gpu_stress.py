@@ -57,3 +57,51 @@ def test_winograd_conv_random_shapes(seed):
         ref = torch.nn.functional.conv2d(ref_in, wt.double(), b.double(), padding=1)
         ref = ref.clamp(min=0) if conv.relu else ref
         assert float((y.double() - ref).abs().max()) <= 3e-5 * max(float(ref.abs().max()), 1.0), (B, cin, cout, h, w)
+
+
+@pytest.mark.parametrize('kind,score_thr', [('A', 0.7), ('A', 0.8), ('B', 0.95), ('A', 0.9)])
+def test_few_survivors_keep_concatenation_order(oracle_lib, kind, score_thr):
+    """bbox_nms.py:52-56: with at most max_num survivors the result is NOT sorted by score but
+    keeps the class-major concatenation -- whole path (both layouts, lazy and complete) vs oracle"""
+    from iouaware import ops
+    ph, pw, B = 128, 160, 2
+    cls, reg, iou = synth.head_outputs(55, B, ph, pw, kind)
+    geom, base = G.geometry(ph, pw, 1000)
+    metas = [synth.img_meta(120, 157, ph, pw, 1.0) for _ in range(B)]
+    shapes, sfs = [m['img_shape'] for m in metas], [m['scale_factor'] for m in metas]
+    want = [oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
+                                         [x[b] for x in iou], synth.STRIDES, base, (120, 157), 1.0,
+                                         True, 1000, score_thr, 0.5, 100) for b in range(B)]
+    assert any(0 < w['num_det'] < 100 for w in want), [w['num_det'] for w in want]
+    for cl in (False, True):
+        dev = [G.to_dev(x) for x in (cls, reg, iou)]
+        if cl:
+            dev = [[t.contiguous(memory_format=torch.channels_last) for t in x] for x in dev]
+        for lazy in (True, False):
+            dets, labels, rows, num = ops.get_bboxes(geom, *dev, shapes, sfs, True, score_thr, 0.5,
+                                                     100, lazy=lazy)
+            for b in range(B):
+                n = int(num[b])
+                assert n == want[b]['num_det']
+                assert np.array_equal(labels[b, :n].cpu().numpy(), want[b]['det_labels']), (cl, lazy)
+                assert np.array_equal(rows[b, :n].cpu().numpy(), want[b]['det_rows'])
+                assert G.same_bits(dets[b, :n].cpu().numpy(), want[b]['det_bboxes'])
+
+
+def test_soft_multiclass_few_survivors_order(oracle_lib):
+    from iouaware import ops
+    rs = np.random.RandomState(3)
+    R, Cn = 200, 5
+    Rs = (R + 63) // 64 * 64
+    xy = rs.uniform(0, 300, (1, R, 2)); wh = rs.uniform(5, 60, (1, R, 2))
+    boxes = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+    scores = np.zeros((1, Cn, Rs), np.float32)
+    scores[0, :, :R] = (rs.uniform(0, 1, (Cn, R)) ** 8).astype(np.float32)
+    out = ops.multiclass_soft_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), R,
+                                  0.5, 0.3, 100, method='linear', sigma=0.5, min_score=0.05)
+    r = oracle_lib.multiclass_soft_nms(boxes[0], scores[0, :, :R].T.copy(), 0.5, 0.3, 'linear', 0.5,
+                                       0.05, 100)
+    n = int(out[3][0])
+    assert 0 < n < 100 and n == r['det_bboxes'].shape[0]
+    assert np.array_equal(out[1][0, :n].cpu().numpy(), r['det_labels'])
+    assert G.same_bits(out[0][0, :n].cpu().numpy(), r['det_bboxes'])
