@@ -105,3 +105,58 @@ def test_soft_multiclass_few_survivors_order(oracle_lib):
     assert 0 < n < 100 and n == r['det_bboxes'].shape[0]
     assert np.array_equal(out[1][0, :n].cpu().numpy(), r['det_labels'])
     assert G.same_bits(out[0][0, :n].cpu().numpy(), r['det_bboxes'])
+
+
+@pytest.mark.parametrize('scales_per_octave,ratios', [(1, [0.5, 1.0, 2.0]), (2, [1.0]), (3, [0.5, 2.0])])
+def test_other_anchor_counts_both_layouts(oracle_lib, scales_per_octave, ratios):
+    """A != 9 (3, 2, 6 anchors per position), fewer levels: whole path vs oracle, both layouts"""
+    from iouaware import ops
+    strides = [8, 16, 32]
+    ph, pw, B, Cn = 96, 160, 2, 80
+    sizes = synth.level_shapes(ph, pw, strides)
+    base = oracle_lib.head_base_anchors(strides, 4, scales_per_octave, ratios)
+    A = base.shape[1]
+    geom = ops.HeadGeometry(sizes, strides, base, Cn, nms_pre=150)
+    rs = np.random.RandomState(A)
+    cls = [(rs.standard_normal((B, A * Cn, h, w)) * 2 - 4).astype(np.float32) for (h, w) in sizes]
+    reg = [(rs.standard_normal((B, A * 4, h, w)) * 0.5).astype(np.float32) for (h, w) in sizes]
+    iou = [(rs.standard_normal((B, A, h, w)) * 1.5).astype(np.float32) for (h, w) in sizes]
+    for cl in (False, True):
+        dev = [G.to_dev(x) for x in (cls, reg, iou)]
+        if cl:
+            dev = [[t.contiguous(memory_format=torch.channels_last) for t in x] for x in dev]
+        dets, labels, rows, num = ops.get_bboxes(geom, *dev, [(90, 155, 3)] * B, [1.0, 0.7], True,
+                                                 0.05, 0.5, 100)
+        for b, sf in enumerate((1.0, 0.7)):
+            o = oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
+                                             [x[b] for x in iou], strides, base, (90, 155), sf, True,
+                                             150, 0.05, 0.5, 100)
+            n = int(num[b])
+            assert n == o['num_det']
+            assert np.array_equal(labels[b, :n].cpu().numpy(), o['det_labels']), (A, cl)
+            assert np.array_equal(rows[b, :n].cpu().numpy(), o['det_rows'])
+            assert G.same_bits(dets[b, :n].cpu().numpy(), o['det_bboxes'])
+
+
+def test_linear_bias_act_random_shapes():
+    from iouaware import ops
+    rs = np.random.RandomState(11)
+    g = torch.Generator(device='cuda').manual_seed(11)
+    for _ in range(8):
+        B, k, n = int(rs.randint(1, 4)), int(rs.choice([3, 16, 64, 100, 512])), int(rs.choice([4, 7, 64, 256]))
+        h, w = int(rs.randint(1, 30)), int(rs.randint(1, 30))
+        x = torch.randn(B, k, h, w, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(n, k, device='cuda', generator=g) * (1.0 / k) ** 0.5
+        bias = torch.randn(n, device='cuda', generator=g) if rs.randint(0, 2) else None
+        res = torch.randn(B, n, h, w, device='cuda', generator=g).contiguous(
+            memory_format=torch.channels_last) if rs.randint(0, 2) else None
+        relu = bool(rs.randint(0, 2))
+        got = ops.linear_bias_act(x, wt.t().contiguous(), bias, residual=res, relu=relu)
+        ref = torch.einsum('bkhw,nk->bnhw', x.double(), wt.double())
+        if bias is not None:
+            ref = ref + bias.double().view(1, -1, 1, 1)
+        if res is not None:
+            ref = ref + res.double()
+        ref = ref.clamp(min=0) if relu else ref
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1.0), (B, k, n, h, w)
