@@ -32,7 +32,7 @@
 
 namespace ia {
 
-constexpr int kLazyMax = 2048;        // candidates walked per image at most
+constexpr int kLazyMax = 4096;        // candidates walked per image at most (LDS: 133 KB of 160 KB)
 constexpr int kLazyParts = 16;
 constexpr int kLazyThreads = 1024;
 
