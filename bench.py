@@ -228,13 +228,13 @@ def main():
     stepper.rowmax_ms = []
 
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper.step(timed=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     stepper.collect()
@@ -274,7 +274,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
