@@ -236,6 +236,11 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
 int ia_linear_bias_act(const float *A, const float *W, const float *bias, const float *residual,
                        float *D, int64_t rows, int k, int n, int relu, void *workspace,
                        size_t workspace_bytes, void *stream);
+/* The same with bf16 operands (A, W, residual, D bf16; bias fp32; fp32 accumulation) for the
+ * bf16 configuration (BASELINE config 3).                                                    */
+int ia_linear_bias_act_bf16(const void *A, const void *W, const float *bias, const void *residual,
+                            void *D, int64_t rows, int k, int n, int relu, void *workspace,
+                            size_t workspace_bytes, void *stream);
 /* The batched GEMM between the Winograd transforms, D[b] (rows, n) = A[b] (rows, k) . W[b] (k, n),
  * b < batch, contiguous row-major stacks; same library, same per-shape candidate timing.      */
 int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows, int k, int n,

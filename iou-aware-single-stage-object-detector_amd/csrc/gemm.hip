@@ -18,7 +18,7 @@ namespace ia {
 struct LtState {
     hipblasLtHandle_t handle = nullptr;
     std::mutex mu;
-    std::map<std::tuple<int64_t, int, int, int, int>, hipblasLtMatmulAlgo_t> algos;
+    std::map<std::tuple<int64_t, int, int, int, int, int>, hipblasLtMatmulAlgo_t> algos;
 };
 
 static LtState &lt_state()
@@ -30,10 +30,13 @@ static LtState &lt_state()
 static int lt_status(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS ? 0 : 2000 + (int)s; }
 
 // batch > 1: strided batched, A / W / D advance by rows*k / k*n / rows*n per matrix
-static int lt_matmul(const float *A, const float *W, const float *bias, const float *residual,
-                     float *D, int64_t rows, int k, int n, int relu, int batch, void *workspace,
-                     size_t workspace_bytes, void *stream)
+// dtype: IA_F32, or IA_BF16 (A / W / residual / D bf16, bias fp32, fp32 accumulation)
+static int lt_matmul(const void *A, const void *W, const float *bias, const void *residual,
+                     void *D, int64_t rows, int k, int n, int relu, int batch, int dtype,
+                     void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    const hipDataType dt = (dtype == IA_F32) ? HIP_R_32F : HIP_R_16BF;
     if (!A || !W || !D || rows < 1 || k < 1 || n < 1 || batch < 1 || residual == D || A == D)
         return IA_E_ARG;
     if (workspace_bytes && !workspace) return IA_E_ARG;
@@ -61,11 +64,14 @@ static int lt_matmul(const float *A, const float *W, const float *bias, const fl
     hipblasLtEpilogue_t ep = bias ? (relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS)
                                   : (relu ? HIPBLASLT_EPILOGUE_RELU : HIPBLASLT_EPILOGUE_DEFAULT);
     IA_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)));
-    if (bias)
+    if (bias) {
         IA_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-    IA_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_32F, (uint64_t)n, (uint64_t)k, (int64_t)n));
-    IA_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_32F, (uint64_t)k, (uint64_t)rows, (int64_t)k));
-    IA_LT(hipblasLtMatrixLayoutCreate(&lc, HIP_R_32F, (uint64_t)n, (uint64_t)rows, (int64_t)n));
+        const hipDataType bt = HIP_R_32F;
+        IA_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+    }
+    IA_LT(hipblasLtMatrixLayoutCreate(&la, dt, (uint64_t)n, (uint64_t)k, (int64_t)n));
+    IA_LT(hipblasLtMatrixLayoutCreate(&lb, dt, (uint64_t)k, (uint64_t)rows, (int64_t)k));
+    IA_LT(hipblasLtMatrixLayoutCreate(&lc, dt, (uint64_t)n, (uint64_t)rows, (int64_t)n));
     if (batch > 1) {
         const int32_t bc = batch;
         const int64_t sa = (int64_t)k * n, sb = rows * k, sc = rows * n;
@@ -78,9 +84,9 @@ static int lt_matmul(const float *A, const float *W, const float *bias, const fl
         }
     }
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
-    const float *C = residual ? residual : D;
+    const void *C = residual ? residual : D;
     const int flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (residual ? 4 : 0);
-    const auto key = std::make_tuple(rows, k, n, flags, batch);
+    const auto key = std::make_tuple(rows, k, n, flags, batch, dtype);
     auto it = st.algos.find(key);
     if (it == st.algos.end()) {
         IA_LT(hipblasLtMatmulPreferenceCreate(&pref));
@@ -129,13 +135,22 @@ extern "C" int ia_linear_bias_act(const float *A, const float *W, const float *b
                                   const float *residual, float *D, int64_t rows, int k, int n,
                                   int relu, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return ia::lt_matmul(A, W, bias, residual, D, rows, k, n, relu, 1, workspace, workspace_bytes,
-                         stream);
+    return ia::lt_matmul(A, W, bias, residual, D, rows, k, n, relu, 1, IA_F32, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int ia_linear_bias_act_bf16(const void *A, const void *W, const float *bias,
+                                       const void *residual, void *D, int64_t rows, int k, int n,
+                                       int relu, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    return ia::lt_matmul(A, W, bias, residual, D, rows, k, n, relu, 1, IA_BF16, workspace,
+                         workspace_bytes, stream);
 }
 
 extern "C" int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows,
                                int k, int n, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return ia::lt_matmul(A, W, nullptr, nullptr, D, rows, k, n, 0, batch, workspace,
+    return ia::lt_matmul(A, W, nullptr, nullptr, D, rows, k, n, 0, batch, IA_F32, workspace,
                          workspace_bytes, stream);
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
     'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
                                       C.POINTER(WinoSeg), _vp]),
     'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    'ia_linear_bias_act_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_batched_gemm': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),

@@ -54,11 +54,14 @@ def _bottleneck_forward(self, x):
     if not _fast(self, x):
         return type(self).forward(self, x)
     f = self._ia_fused
-    lt = 'w1' in f and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    lt = 'w1' in f and x.dtype in (torch.float32, torch.bfloat16) \
+        and x.is_contiguous(memory_format=torch.channels_last)
     if lt:
         # 1x1 convolutions = library GEMMs on the channels-last activation, folded BN / residual /
-        # ReLU in the GEMM epilogue (csrc/gemm.hip)
-        out, pre = ops.linear_bias_act(x, f['w1'], f['b1'], relu=True), None
+        # ReLU in the GEMM epilogue (csrc/gemm.hip); bf16 networks use bf16 copies of the folded
+        # weights (biases stay fp32, accumulation is fp32)
+        w = _weights_for(f, x.dtype)
+        out, pre = ops.linear_bias_act(x, w['w1'], f['b1'], relu=True), None
     else:
         out, pre = self.conv1(x), (f['s1'], f['b1'], True)
     wino = f.get('wino2')
@@ -71,19 +74,32 @@ def _bottleneck_forward(self, x):
         out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
     if lt and out.is_contiguous(memory_format=torch.channels_last):
         if self.downsample is None:
-            return ops.linear_bias_act(out, f['w3'], f['b3'], residual=x, relu=True)
+            return ops.linear_bias_act(out, w['w3'], f['b3'], residual=x, relu=True)
         if 'wd' in f:                     # stride-1 projection: a GEMM as well
-            idn = ops.linear_bias_act(x, f['wd'], f['b3d'])
-            return ops.linear_bias_act(out, f['w3'], None, residual=idn, relu=True)
+            idn = ops.linear_bias_act(x, w['wd'], f['b3d'])
+            return ops.linear_bias_act(out, w['w3'], None, residual=idn, relu=True)
         ds = self.downsample[0]
-        idn = F.conv2d(x, f['wd_conv'], None, ds.stride, ds.padding)
-        return ops.linear_bias_act(out, f['w3'], f['b3d'], residual=idn, relu=True)
+        idn = F.conv2d(x, w['wd_conv'], None, ds.stride, ds.padding)
+        return ops.linear_bias_act(out, w['w3'], f['b3d'], residual=idn, relu=True)
     out = self.conv3(out)
     if self.downsample is None:
         return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True)
     idn = self.downsample[0](x)
     return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=idn, res_scale=f['sd'],
                                    res_shift=f['bd'], relu=True)
+
+
+def _weights_for(f, dtype):
+    """the folded GEMM weights of a fused module in the activation dtype (fp32 originals; other
+    dtypes are cast once and cached)"""
+    if dtype == torch.float32:
+        return f
+    cache = f.setdefault('_cast', {})
+    w = cache.get(dtype)
+    if w is None:
+        w = cache[dtype] = {k: v.to(dtype) for k, v in f.items()
+                            if k in ('w1', 'w3', 'wd', 'wd_conv', 'w_kn')}
+    return w
 
 
 def _basic_forward(self, x):
@@ -126,9 +142,9 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     wino = f.get('wino')
     if wino is not None and wino.relu == relu and wino.usable(x):
         return wino(x)
-    if 'w_kn' in f and norm and x.dtype == torch.float32 \
+    if 'w_kn' in f and norm and x.dtype in (torch.float32, torch.bfloat16) \
             and x.is_contiguous(memory_format=torch.channels_last):
-        return ops.linear_bias_act(x, f['w_kn'], f['b_kn'], relu=relu)      # 1x1 conv = GEMM
+        return ops.linear_bias_act(x, _weights_for(f, x.dtype)['w_kn'], f['b_kn'], relu=relu)
     if self.with_norm and norm:
         y = self.conv(x)                      # conv before a norm has no bias
         return ops.channel_affine_act_(y, f['s'], f['b'], relu=relu)

@@ -448,16 +448,27 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False):
     _require_gpu(x, 'x')
     B, k, H, W = x.shape
     n = int(w_kn.shape[1])
-    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
-        raise TypeError('linear_bias_act needs a channels-last fp32 activation')
-    if tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous():
-        raise ValueError('weight must be a contiguous (k, n) matrix')
-    out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device,
+    if x.dtype not in (torch.float32, torch.bfloat16) or \
+            not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('linear_bias_act needs a channels-last fp32 / bf16 activation')
+    if tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous() or w_kn.dtype != x.dtype:
+        raise ValueError('weight must be a contiguous (k, n) matrix of the activation dtype')
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError('bias must be fp32')
+    out = torch.empty((B, n, H, W), dtype=x.dtype, device=x.device,
                       memory_format=torch.channels_last)
     if residual is not None and (tuple(residual.shape) != tuple(out.shape) or
                                  not residual.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError('residual must be a channels-last tensor of the output shape')
+    if residual is not None and residual.dtype != x.dtype:
+        raise TypeError('residual dtype mismatch')
     ws = _workspace(x.device, _LT_WS_BYTES)
+    if x.dtype == torch.bfloat16:
+        _lib.check(_lib.lib().ia_linear_bias_act_bf16(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual),
+                                                      _ptr(out), B * H * W, k, n, int(bool(relu)),
+                                                      _ptr(ws), _LT_WS_BYTES, _stream()),
+                   'ia_linear_bias_act_bf16')
+        return out
     _lib.check(_lib.lib().ia_linear_bias_act(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual),
                                              _ptr(out), B * H * W, k, n, int(bool(relu)), _ptr(ws),
                                              _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')

@@ -136,3 +136,49 @@ def test_upsample2x_add_matches_torch():
         want = fine + torch.nn.functional.interpolate(coarse, scale_factor=2, mode='nearest')
         got = ops.upsample2x_add_(fine, coarse)
         assert got.data_ptr() == fine.data_ptr() and torch.equal(got, want)
+
+
+def test_linear_bias_act_bf16():
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(2, 256, 25, 42, device='cuda', generator=g).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    w = (torch.randn(64, 256, device='cuda', generator=g) * 0.06).to(torch.bfloat16)
+    b = torch.randn(64, device='cuda', generator=g)
+    r = torch.randn(2, 64, 25, 42, device='cuda', generator=g).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    got = ops.linear_bias_act(x, w.t().contiguous(), b, residual=r, relu=True)
+    assert got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.einsum('bkhw,nk->bnhw', x.double(), w.double()) + b.double().view(1, -1, 1, 1) + r.double()
+    ref = ref.clamp(min=0)
+    assert float((got.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())    # bf16 output
+
+
+def test_fused_bf16_network_matches_unfused():
+    """BASELINE config 3 dtype: the fused path (bf16 hipBLASLt 1x1 GEMMs, bf16 epilogues) vs the
+    plain bf16 modules, relative to the activation scale"""
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    import bench
+    torch.manual_seed(0)
+    m = iouaware.build_detector(ConfigDict(bench.MODEL), test_cfg=ConfigDict(bench.TEST_CFG)).cuda().eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_var.uniform_(0.5, 1.5); mod.weight.uniform_(0.5, 1.5)
+        for p in m.bbox_head.parameters():
+            if p.dim() == 4:
+                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
+    fuse_inference(m, winograd=True)
+    m = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
+    x = torch.randn(2, 3, 224, 288, device='cuda').to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = m.forward_head(x)
+        unfuse_inference(m)
+        ref = m.forward_head(x)
+    for a, b in zip(ref, out):
+        for u, v in zip(a, b):
+            assert v.dtype == torch.bfloat16
+            assert float((u.float() - v.float()).abs().max()) <= 0.08 * float(u.float().abs().max())
