@@ -20,7 +20,6 @@ the folded form x*scale+shift differs from it by rounding only.
 import types
 
 import torch
-import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
