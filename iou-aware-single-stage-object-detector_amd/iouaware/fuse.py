@@ -155,7 +155,6 @@ def _convmodule_forward(self, x, activate=True, norm=True):
 
 def _fpn_forward(self, inputs):
     """FPN.forward with the top-down `lat[i-1] + interpolate(lat[i])` as one in-place kernel"""
-    import torch.nn.functional as F_
     lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
     n = len(lat)
     ok = (not self.training) and (not torch.is_grad_enabled()) and all(
@@ -167,17 +166,17 @@ def _fpn_forward(self, inputs):
         if lat[i - 1].shape[2] == 2 * lat[i].shape[2] and lat[i - 1].shape[3] == 2 * lat[i].shape[3]:
             ops.upsample2x_add_(lat[i - 1], lat[i])
         else:
-            lat[i - 1] = lat[i - 1] + F_.interpolate(lat[i], scale_factor=2, mode='nearest')
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], scale_factor=2, mode='nearest')
     outs = [self.fpn_convs[i](lat[i]) for i in range(n)]
     if self.num_outs > n:
         if not self.add_extra_convs:
             for _ in range(self.num_outs - n):
-                outs.append(F_.max_pool2d(outs[-1], 1, stride=2))
+                outs.append(F.max_pool2d(outs[-1], 1, stride=2))
         else:
             first = inputs[self.backbone_end_level - 1] if self.extra_convs_on_inputs else outs[-1]
             outs.append(self.fpn_convs[n](first))
             for i in range(n + 1, self.num_outs):
-                src = F_.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
+                src = F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
                 outs.append(self.fpn_convs[i](src))
     return tuple(outs)
 
