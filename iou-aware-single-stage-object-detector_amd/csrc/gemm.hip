@@ -16,7 +16,9 @@
 namespace ia {
 
 struct LtState {
-    hipblasLtHandle_t handle = nullptr;
+    // one library handle per stream: a handle owns device-side argument buffers, so launches that
+    // may overlap on different streams must not share one
+    std::map<hipStream_t, hipblasLtHandle_t> handles;
     std::mutex mu;
     std::map<std::tuple<int64_t, int, int, int, int, int>, hipblasLtMatmulAlgo_t> algos;
 };
@@ -43,8 +45,9 @@ static int lt_matmul(const void *A, const void *W, const float *bias, const void
     ia::LtState &st = ia::lt_state();
     std::lock_guard<std::mutex> lock(st.mu);
     int rc;
-    if (!st.handle && (rc = ia::lt_status(hipblasLtCreate(&st.handle)))) return rc;
     hipStream_t s = (hipStream_t)stream;
+    hipblasLtHandle_t &handle = st.handles[s];
+    if (!handle && (rc = ia::lt_status(hipblasLtCreate(&handle)))) return rc;
 
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
@@ -94,7 +97,7 @@ static int lt_matmul(const void *A, const void *W, const float *bias, const void
                                                     &workspace_bytes, sizeof(workspace_bytes)));
         hipblasLtMatmulHeuristicResult_t res[16];
         int nres = 0;
-        IA_LT(hipblasLtMatmulAlgoGetHeuristic(st.handle, desc, la, lb, lc, lc, pref, 16, res, &nres));
+        IA_LT(hipblasLtMatmulAlgoGetHeuristic(handle, desc, la, lb, lc, lc, pref, 16, res, &nres));
         if (nres < 1) { cleanup(); return IA_E_ARG; }
         // first call of this shape: time the candidates on the caller's stream (the output is
         // simply rewritten; C != D, so every run computes the same result)
@@ -105,12 +108,12 @@ static int lt_matmul(const void *A, const void *W, const float *bias, const void
             for (int a = 0; a < nres; ++a) {
                 bool ok = true;
                 for (int r = 0; r < 2 && ok; ++r)
-                    ok = hipblasLtMatmul(st.handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
+                    ok = hipblasLtMatmul(handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
                                          &res[a].algo, workspace, workspace_bytes, s) == HIPBLAS_STATUS_SUCCESS;
                 if (!ok) continue;
                 (void)hipEventRecord(e0, s);
                 for (int r = 0; r < 4; ++r)
-                    hipblasLtMatmul(st.handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
+                    hipblasLtMatmul(handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
                                     &res[a].algo, workspace, workspace_bytes, s);
                 (void)hipEventRecord(e1, s);
                 (void)hipEventSynchronize(e1);
@@ -122,7 +125,7 @@ static int lt_matmul(const void *A, const void *W, const float *bias, const void
         }
         it = st.algos.emplace(key, res[best].algo).first;
     }
-    rc = ia::lt_status(hipblasLtMatmul(st.handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
+    rc = ia::lt_status(hipblasLtMatmul(handle, desc, &alpha, W, la, A, lb, &beta, C, lc, D, lc,
                                        &it->second, workspace, workspace_bytes, s));
 #undef IA_LT
     cleanup();
