@@ -160,3 +160,40 @@ def test_linear_bias_act_random_shapes():
         ref = ref.clamp(min=0) if relu else ref
         assert got.shape == ref.shape
         assert float((got.double() - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1.0), (B, k, n, h, w)
+
+
+def test_two_streams_give_the_single_stream_result():
+    """whole fused inference path issued on two side streams at once (scratch buffers, workspaces
+    and the GEMM library handle are per stream) == the default-stream result, repeatedly"""
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    from test_host_model import R50_MODEL, TEST_CFG
+    torch.manual_seed(1)
+    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).cuda().eval()
+    with torch.no_grad():
+        for p in m.bbox_head.parameters():
+            if p.dim() == 4:
+                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
+    fuse_inference(m, winograd=True)
+    m = m.to(memory_format=torch.channels_last)
+    xs = [torch.randn(2, 3, 192, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+          for _ in range(2)]
+    metas = [synth.img_meta(190, 250, 192, 256) for _ in range(2)]
+    with torch.no_grad():
+        ref = [m.simple_test_device(x, metas, rescale=True) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        for _ in range(5):
+            outs = []
+            cur = torch.cuda.current_stream()
+            for s, x in zip(streams, xs):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    outs.append(m.simple_test_device(x, metas, rescale=True))
+            for s in streams:
+                cur.wait_stream(s)
+            torch.cuda.synchronize()
+            for r, o in zip(ref, outs):
+                assert torch.equal(r[3], o[3]) and torch.equal(r[1], o[1])
+                assert float((r[0] - o[0]).abs().max()) < 1e-3          # MIOpen may pick other algos
