@@ -146,7 +146,8 @@ int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int 
  * is kept iff no already kept pair of its class suppresses it; max_per_img survivors end the
  * walk -- greedy per-class NMS decides a box from higher-ranked boxes only, so these are exactly
  * the detections multiclass_nms returns (bbox_nms.py:33-56), without resolving 80 complete class
- * problems.  candidates: pairs walked per image at most (0 = default 4096); an image that runs
+ * problems.  candidates: pairs walked per image at most (0 = default: 1024, then 4096 for the
+ * images that need more); an image that runs
  * out of them with fewer than max_per_img survivors takes the complete path.  The per-class
  * keep lists in the workspace are NOT produced by this entry point.                        */
 int ia_get_bboxes_lazy(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,

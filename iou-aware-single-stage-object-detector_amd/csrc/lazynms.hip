@@ -33,6 +33,7 @@
 namespace ia {
 
 constexpr int kLazyMax = 4096;        // candidates walked per image at most (LDS: 133 KB of 160 KB)
+constexpr int kLazyFirst = 1024;      // first, cheap walk of the default two-tier schedule
 constexpr int kLazyParts = 16;
 constexpr int kLazyThreads = 1024;
 
@@ -47,6 +48,7 @@ struct LazyArgs {
     IouThr thr;
     float score_thr;
     int32_t R, Rs, C, M, max_per_img;
+    const int32_t *gate;              // optional (B): second, larger walk only where the first failed
 };
 
 __global__ void __launch_bounds__(256) k_lazy_keys(LazyArgs a)
@@ -96,6 +98,7 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_part(LazyArgs a)
     __shared__ uint64_t sel[kLazyMax];
     const int part = blockIdx.x, b = blockIdx.y;
     const uint32_t tid = threadIdx.x;
+    if (a.gate && !a.gate[b]) return;
     const uint32_t total = (uint32_t)a.count[b], M = (uint32_t)a.M;
     if (total <= M) return;                                // the greedy kernel reads `flat` directly
     uint64_t *out = a.part_keys + ((size_t)b * kLazyParts + part) * M;
@@ -129,6 +132,7 @@ __global__ void __launch_bounds__(kLazyThreads) k_lazy_greedy(LazyArgs a)
     LazySmem &sm = *reinterpret_cast<LazySmem *>(dyn);
     const int b = blockIdx.x;
     const uint32_t tid = threadIdx.x;
+    if (a.gate && !a.gate[b]) return;
     const uint32_t total = (uint32_t)a.count[b], M = (uint32_t)a.M;
     const uint32_t m = (total < M) ? total : M;
     // ---- the m globally best pairs of the image, sorted (score desc, class asc, row asc)
@@ -246,11 +250,15 @@ int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R,
     if ((uint64_t)C * (uint64_t)Rs > 0x7fffffffull) return IA_E_ARG;
     if (!boxes || !scores_t || !workspace || !dets || !labels || !rows || !num || !need_full)
         return IA_E_ARG;
-    if (candidates <= 0) candidates = kLazyMax;
+    // candidates == 0: two tiers -- a short walk (kLazyFirst pairs, enough for most images) and,
+    // only for the images it could not finish, a long one (kLazyMax) before the complete path
+    const bool two_tier = candidates <= 0 && max_per_img < kLazyFirst;
+    if (candidates <= 0) candidates = two_tier ? kLazyFirst : kLazyMax;
     if (candidates > kLazyMax) candidates = kLazyMax;
     if (candidates <= max_per_img) candidates = max_per_img + 1;   // the walk needs cap + 1 survivors
     if (candidates > kLazyMax) candidates = kLazyMax;
     LazyArgs a;
+    a.gate = nullptr;
     char *ws = static_cast<char *>(workspace);
     a.flat = reinterpret_cast<uint64_t *>(ws);
     ws += lazy_align((size_t)batch * C * Rs * sizeof(uint64_t));
@@ -270,6 +278,12 @@ int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R,
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lazy_greedy),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LazySmem));
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_lazy_greedy, dim3((unsigned)batch), dim3(kLazyThreads), sizeof(LazySmem), s, a);
+    if ((rc = hip_status(hipGetLastError())) || !two_tier) return rc;
+    a.M = kLazyMax;
+    a.gate = need_full;               // read at kernel start, rewritten by the same workgroup at its end
+    hipLaunchKernelGGL(k_lazy_part, dim3(kLazyParts, (unsigned)batch), dim3(kLazyThreads), 0, s, a);
+    if ((rc = hip_status(hipGetLastError()))) return rc;
     hipLaunchKernelGGL(k_lazy_greedy, dim3((unsigned)batch), dim3(kLazyThreads), sizeof(LazySmem), s, a);
     return hip_status(hipGetLastError());
 }

@@ -200,3 +200,35 @@ def test_two_streams_give_the_single_stream_result():
                 assert torch.equal(r[3], o[3])
                 assert float((r[1] == o[1]).float().mean()) > 0.9
                 assert float(((r[0] - o[0]).abs().amax(-1) < 1e-3).float().mean()) > 0.9
+
+
+@pytest.mark.parametrize('per_cluster', [10, 60, 200])
+def test_lazy_two_tier_clustered_scenes(per_cluster):
+    """clusters of near-identical high-scoring boxes: the 101st survivor lies behind ~3*20*per_cluster
+    pairs -- inside the short walk (10), only inside the long one (60), or behind both so that the
+    complete path takes over (200); default two-tier lazy NMS == complete NMS in every case"""
+    from iouaware import ops
+    rs = np.random.RandomState(per_cluster)
+    R, Cn, ncl = 4693, 3, 20
+    Rs = (R + 63) // 64 * 64
+    boxes = np.zeros((2, R, 4), np.float32)
+    scores = np.zeros((2, Cn, Rs), np.float32)
+    for b in range(2):
+        k = 0
+        for c in range(ncl):
+            cx, cy = rs.uniform(100, 1200), rs.uniform(100, 700)
+            for _ in range(per_cluster):
+                j = rs.uniform(-2, 2, 4)
+                boxes[b, k] = [cx - 40 + j[0], cy - 40 + j[1], cx + 40 + j[2], cy + 40 + j[3]]
+                scores[b, :, k] = rs.uniform(0.5, 0.95, Cn)
+                k += 1
+        n_iso = R - k
+        xy = rs.uniform(0, 1300, (n_iso, 2)); wh = rs.uniform(8, 30, (n_iso, 2))
+        boxes[b, k:] = np.concatenate([xy, xy + wh], 1)
+        scores[b, :, k:R] = rs.uniform(0.06, 0.45, (Cn, n_iso))
+    bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    full = ops.multiclass_nms(bt, st, R, 0.05, 0.5, 100)[:4]
+    lz = ops.multiclass_nms_lazy(bt, st, R, 0.05, 0.5, 100)
+    assert int(full[3].min()) == 100
+    for name, a, b in zip(('dets', 'labels', 'rows', 'num'), full, lz):
+        assert torch.equal(a, b), (per_cluster, name)
