@@ -25,6 +25,8 @@ torch.cuda.synchronize(); t = time.time(); n = 5
 for _ in range(n): lv = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
 torch.cuda.synchronize(); dt = (time.time() - t) / n
 print('B=%d  %.1f ms/iter  %.1f img/s  loss %s  mem %.1f GB' % (B, dt * 1e3, B / dt, {k: round(v, 4) for k, v in lv.items()}, torch.cuda.max_memory_allocated() / 1e9))
+if os.environ.get('TRAIN_ONLY'):
+    sys.exit(0)
 # loss part alone (targets + 3 losses fwd + bwd) on fixed head outputs
 with torch.no_grad():
     outs = model.bbox_head(model.extract_feat(img))
