@@ -34,11 +34,16 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
     return dict(missing=missing, unexpected=unexpected, mismatched=mismatched)
 
 
-def load_checkpoint(model, filename, map_location=None, strict=False, logger=None):
+def load_checkpoint(model, filename, map_location=None, strict=False, logger=None,
+                    allow_pickle=False):
+    """Reference checkpoints hold tensors and a plain 'meta' dict, so the safe unpickler
+    (weights_only=True) is the default; allow_pickle=True opts into torch's full unpickler for
+    files that carry other Python objects -- only for files you trust."""
     if filename.startswith(('modelzoo://', 'open-mmlab://', 'http://', 'https://')):
         raise IOError('no network in this build: download %s yourself and pass a local path'
                       % filename)
-    ckpt = torch.load(filename, map_location=map_location or 'cpu', weights_only=False)
+    ckpt = torch.load(filename, map_location=map_location or 'cpu',
+                      weights_only=not allow_pickle)
     if isinstance(ckpt, dict) and 'state_dict' in ckpt:
         sd = ckpt['state_dict']
     elif isinstance(ckpt, dict):

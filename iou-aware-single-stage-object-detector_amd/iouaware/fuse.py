@@ -11,8 +11,9 @@ which is a full read+write pass over the activation:
     ConvModule (conv_module.py:149-163):       bias add, relu  ->  1 pass
 
 Parameters and state_dict are untouched (checkpoints still load); the folded
-per-channel scale/shift are recomputed from the BatchNorm buffers by
-`fuse_inference`, so call it AFTER loading weights.  Only eval-mode, no-grad,
+per-channel scale/shift and weight copies are derived from them by `fuse_inference`
+and derived AGAIN whenever the source tensors change (stamp check in every fused
+forward: checkpoint loads, optimizer steps, `.to()` are all safe after fusing).  Only eval-mode, no-grad,
 GPU forwards take the fused route; anything else falls back to the module's
 ordinary forward.  BatchNorm in eval mode is y = (x-mean)/sqrt(var+eps)*g + b;
 the folded form x*scale+shift differs from it by rounding only.
@@ -40,9 +41,29 @@ def _fold_bn(bn):
     return scale.contiguous(), shift.contiguous()
 
 
+def _stamp(module):
+    """identity + version of what the folded copies were derived from: every convolution weight
+    and one running statistic per BatchNorm under `module`.  An optimizer step, a checkpoint
+    load (in-place copies bump `_version`) or `.to(device / dtype)` (new storage) changes it."""
+    out = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            out.append((m.weight.data_ptr(), m.weight._version))
+            if m.bias is not None:
+                out.append((m.bias.data_ptr(), m.bias._version))
+        elif isinstance(m, _BatchNorm) and m.running_var is not None:
+            out.append((m.running_var.data_ptr(), m.running_var._version))
+            if m.weight is not None:
+                out.append((m.weight.data_ptr(), m.weight._version))
+    return tuple(out)
+
+
 def _fast(module, x):
-    return (not module.training) and (not torch.is_grad_enabled()) and x.is_cuda \
+    ok = (not module.training) and (not torch.is_grad_enabled()) and x.is_cuda \
         and x.dtype in (torch.float32, torch.bfloat16)
+    if ok and module._ia_stamp != _stamp(module):
+        _fold(module)              # parameters changed since the fold: derive the copies again
+    return ok
 
 
 def _conv_nobias(conv, x):
@@ -155,13 +176,20 @@ def _convmodule_forward(self, x, activate=True, norm=True):
 
 def _fpn_forward(self, inputs):
     """FPN.forward with the top-down `lat[i-1] + interpolate(lat[i])` as one in-place kernel"""
+    # preconditions first: the fall-back recomputes everything, so nothing may run before it.
+    # The lateral convolutions keep the layout / dtype of their inputs and have
+    # out_channels outputs, which is all the fused top-down kernel needs to know.
+    ok = (not self.training) and (not torch.is_grad_enabled()) \
+        and len(inputs) == len(self.in_channels) and self.out_channels % 4 == 0 and all(
+            t.is_cuda and t.dtype == torch.float32
+            and t.is_contiguous(memory_format=torch.channels_last)
+            for t in inputs[self.start_level:self.backbone_end_level])
+    if not ok:
+        return type(self).forward(self, inputs)
     lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
     n = len(lat)
-    ok = (not self.training) and (not torch.is_grad_enabled()) and all(
-        t.is_cuda and t.dtype == torch.float32 and t.shape[1] % 4 == 0
-        and t.is_contiguous(memory_format=torch.channels_last) for t in lat)
-    if not ok or len(inputs) != len(self.in_channels):
-        return type(self).forward(self, inputs)
+    if not all(t.is_contiguous(memory_format=torch.channels_last) for t in lat):
+        lat = [t.contiguous(memory_format=torch.channels_last) for t in lat]
     for i in range(n - 1, 0, -1):
         if lat[i - 1].shape[2] == 2 * lat[i].shape[2] and lat[i - 1].shape[3] == 2 * lat[i].shape[3]:
             ops.upsample2x_add_(lat[i - 1], lat[i])
@@ -184,6 +212,9 @@ def _fpn_forward(self, inputs):
 def _head_forward(self, feats):
     w = self._ia_wino
     if (not self.training) and w.usable(feats):
+        if self._ia_stamp != _stamp(self):
+            _fold(self)
+            w = self._ia_wino
         return w(list(feats))
     return type(self).forward(self, feats)
 
@@ -203,108 +234,146 @@ def _gemm_ok(conv):
             and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.bias is None)
 
 
+def _fold(m):
+    """(re)derive the folded / transformed weight copies of one fused module from its current
+    parameters.  Returns False for modules this file does not fuse."""
+    winograd, fpn_conv = m._ia_opts
+    if type(m).__name__ == 'FPN':
+        return True                               # nothing folded: only the forward is replaced
+    if type(m).__name__ == 'IoUawareRetinaHead':
+        from .winograd import WinogradHead
+        m._ia_wino = WinogradHead(m)
+    elif isinstance(m, Bottleneck):
+        f = {}
+        f['s1'], f['b1'] = _fold_bn(m.norm1)
+        f['s2'], f['b2'] = _fold_bn(m.norm2)
+        f['s3'], f['b3'] = _fold_bn(m.norm3)
+        if m.downsample is not None:
+            f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+        if winograd and _gemm_ok(m.conv1) and _gemm_ok(m.conv3):
+            with torch.no_grad():
+                def kn(conv, scale):       # (Cout, Cin, 1, 1) * scale[Cout] -> (Cin, Cout)
+                    w = conv.weight.float().view(conv.out_channels, conv.in_channels)
+                    return (w * scale.view(-1, 1)).t().contiguous()
+                f['w1'], f['w3'] = kn(m.conv1, f['s1']), kn(m.conv3, f['s3'])
+                if m.downsample is not None:
+                    ds = m.downsample[0]
+                    f['b3d'] = (f['b3'] + f['bd']).contiguous()
+                    if _gemm_ok(ds):
+                        f['wd'] = kn(ds, f['sd'])
+                    else:
+                        f['wd_conv'] = (ds.weight.float() * f['sd'].view(-1, 1, 1, 1)).contiguous(
+                            memory_format=torch.channels_last)
+        if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
+            from .winograd import WinogradConv3x3
+            with torch.no_grad():           # BN scale folded into the weights, shift = bias
+                w2 = m.conv2.weight.float() * f['s2'].view(-1, 1, 1, 1)
+            f['wino2'] = WinogradConv3x3(w2, f['b2'], relu=True)
+        m._ia_fused = f
+    elif isinstance(m, BasicBlock):
+        f = {}
+        f['s1'], f['b1'] = _fold_bn(m.norm1)
+        f['s2'], f['b2'] = _fold_bn(m.norm2)
+        if m.downsample is not None:
+            f['sd'], f['bd'] = _fold_bn(m.downsample[1])
+        m._ia_fused = f
+    elif isinstance(m, ResNet):
+        f = {}
+        f['s'], f['b'] = _fold_bn(m.norm1)
+        mp = m.maxpool
+        f['pool'] = (_pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding),
+                     _pair(mp.dilation), mp.ceil_mode) == ((3, 3), (2, 2), (1, 1), (1, 1), False)
+        m._ia_fused = f
+    elif isinstance(m, ConvModule):
+        f = {}
+        c = m.conv
+        if m.with_norm:
+            if not isinstance(m.norm, _BatchNorm):
+                return False                   # GroupNorm etc.: leave eager
+            f['s'], f['b'] = _fold_bn(m.norm)
+            if c.bias is not None:             # conv bias in front of a norm: (y + bias) * s + b
+                with torch.no_grad():
+                    f['b'] = (f['b'] + c.bias.detach().float() * f['s']).contiguous()
+        elif c.bias is not None:
+            f['bias'] = c.bias.detach().float().contiguous()
+        if winograd and tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) \
+                and tuple(c.padding) == (0, 0) and c.groups == 1:
+            with torch.no_grad():
+                w = c.weight.float().view(c.out_channels, c.in_channels)
+                if m.with_norm:
+                    f['w_kn'], f['b_kn'] = (w * f['s'].view(-1, 1)).t().contiguous(), f['b']
+                else:
+                    f['w_kn'] = w.t().contiguous()
+                    f['b_kn'] = None if c.bias is None else c.bias.detach().float().contiguous()
+        if winograd and fpn_conv and not m.with_norm and _wino_ok(m.conv):
+            from .winograd import WinogradConv3x3
+            f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)
+        m._ia_fused = f
+    else:
+        return False
+    m._ia_stamp = _stamp(m)
+    return True
+
+
+def _forward_for(m, winograd):
+    if type(m).__name__ == 'FPN':
+        return _fpn_forward if winograd else None
+    if type(m).__name__ == 'IoUawareRetinaHead':
+        return _head_forward if winograd else None
+    for cls, fn in ((Bottleneck, _bottleneck_forward), (BasicBlock, _basic_forward),
+                    (ResNet, _resnet_forward), (ConvModule, _convmodule_forward)):
+        if isinstance(m, cls):
+            return fn
+    return None
+
+
 def fuse_inference(model, winograd=False):
     """Patch `model` in place (see module docstring).  Returns the number of fused modules.
 
     winograd=True additionally routes the head's 3x3 convolutions through the Winograd
     F(4x4,3x3) path (iouaware/winograd.py) whenever its inputs are channels-last fp32 CUDA
-    tensors: all pyramid levels in one batched GEMM per layer."""
+    tensors: all pyramid levels in one batched GEMM per layer.
+
+    The folded BatchNorm scale / shift, the GEMM-layout weights and the Winograd-transformed
+    weights are COPIES of the parameters; every fused forward compares a stamp of the source
+    tensors (storage pointer + version counter) and derives the copies again when a checkpoint
+    load, an optimizer step or `.to()` changed them."""
     n = 0
     # FPN output convolutions (per-level weights) take the single-level Winograd path; the head's
-    # ConvModules are bypassed by the head-level runner below
+    # ConvModules are bypassed by the head-level runner
     fpn_convs = set()
     if winograd:
         for m in model.modules():
             if type(m).__name__ == 'FPN':
                 fpn_convs.update(id(c) for c in m.fpn_convs)
     for m in model.modules():
-        if winograd and type(m).__name__ == 'FPN':
-            m._ia_wino = True                     # marker for unfuse_inference
-            m.forward = types.MethodType(_fpn_forward, m)
-            n += 1
+        fwd = _forward_for(m, winograd)
+        if fwd is None:
             continue
-        if winograd and type(m).__name__ == 'IoUawareRetinaHead':
-            from .winograd import WinogradHead
-            m._ia_wino = WinogradHead(m)
-            m.forward = types.MethodType(_head_forward, m)
-            n += 1
+        m._ia_opts = (bool(winograd), id(m) in fpn_convs)
+        if not _fold(m):
+            del m._ia_opts
             continue
-        if isinstance(m, Bottleneck):
-            f = {}
-            f['s1'], f['b1'] = _fold_bn(m.norm1)
-            f['s2'], f['b2'] = _fold_bn(m.norm2)
-            f['s3'], f['b3'] = _fold_bn(m.norm3)
-            if m.downsample is not None:
-                f['sd'], f['bd'] = _fold_bn(m.downsample[1])
-            if winograd and _gemm_ok(m.conv1) and _gemm_ok(m.conv3):
-                with torch.no_grad():
-                    def kn(conv, scale):       # (Cout, Cin, 1, 1) * scale[Cout] -> (Cin, Cout)
-                        w = conv.weight.float().view(conv.out_channels, conv.in_channels)
-                        return (w * scale.view(-1, 1)).t().contiguous()
-                    f['w1'], f['w3'] = kn(m.conv1, f['s1']), kn(m.conv3, f['s3'])
-                    if m.downsample is not None:
-                        ds = m.downsample[0]
-                        f['b3d'] = (f['b3'] + f['bd']).contiguous()
-                        if _gemm_ok(ds):
-                            f['wd'] = kn(ds, f['sd'])
-                        else:
-                            f['wd_conv'] = (ds.weight.float() * f['sd'].view(-1, 1, 1, 1)).contiguous(
-                                memory_format=torch.channels_last)
-            if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
-                from .winograd import WinogradConv3x3
-                with torch.no_grad():           # BN scale folded into the weights, shift = bias
-                    w2 = m.conv2.weight.float() * f['s2'].view(-1, 1, 1, 1)
-                f['wino2'] = WinogradConv3x3(w2, f['b2'], relu=True)
-            m._ia_fused = f
-            m.forward = types.MethodType(_bottleneck_forward, m)
-        elif isinstance(m, BasicBlock):
-            f = {}
-            f['s1'], f['b1'] = _fold_bn(m.norm1)
-            f['s2'], f['b2'] = _fold_bn(m.norm2)
-            if m.downsample is not None:
-                f['sd'], f['bd'] = _fold_bn(m.downsample[1])
-            m._ia_fused = f
-            m.forward = types.MethodType(_basic_forward, m)
-        elif isinstance(m, ResNet):
-            f = {}
-            f['s'], f['b'] = _fold_bn(m.norm1)
-            mp = m.maxpool
-            f['pool'] = (_pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding),
-                         _pair(mp.dilation), mp.ceil_mode) == ((3, 3), (2, 2), (1, 1), (1, 1), False)
-            m._ia_fused = f
-            m.forward = types.MethodType(_resnet_forward, m)
-        elif isinstance(m, ConvModule):
-            f = {}
-            if m.with_norm:
-                if not isinstance(m.norm, _BatchNorm):
-                    continue                   # GroupNorm etc.: leave eager
-                f['s'], f['b'] = _fold_bn(m.norm)
-            elif m.conv.bias is not None:
-                f['bias'] = m.conv.bias.detach().float().contiguous()
-            c = m.conv
-            if winograd and tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) \
-                    and tuple(c.padding) == (0, 0) and c.groups == 1:
-                with torch.no_grad():
-                    w = c.weight.float().view(c.out_channels, c.in_channels)
-                    if m.with_norm:
-                        f['w_kn'], f['b_kn'] = (w * f['s'].view(-1, 1)).t().contiguous(), f['b']
-                    else:
-                        f['w_kn'] = w.t().contiguous()
-                        f['b_kn'] = None if c.bias is None else c.bias.detach().float().contiguous()
-            if winograd and id(m) in fpn_convs and not m.with_norm and _wino_ok(m.conv):
-                from .winograd import WinogradConv3x3
-                f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)
-            m._ia_fused = f
-            m.forward = types.MethodType(_convmodule_forward, m)
-        else:
-            continue
+        if type(m).__name__ == 'FPN':
+            m._ia_stamp = ()
+        m.forward = types.MethodType(fwd, m)
         n += 1
+    return n
+
+
+def refresh_fused(model):
+    """derive the folded copies of every fused module again (after loading weights by means
+    that bypass the stamp, e.g. `param.data = ...`).  Returns the number of modules touched."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, '_ia_opts') and _fold(m):
+            n += 1
     return n
 
 
 def unfuse_inference(model):
     for m in model.modules():
-        for attr in ('_ia_fused', '_ia_wino'):
+        for attr in ('_ia_fused', '_ia_wino', '_ia_opts', '_ia_stamp'):
             if hasattr(m, attr):
                 delattr(m, attr)
                 if 'forward' in m.__dict__:

@@ -73,8 +73,19 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
     n = multi_bboxes.shape[0]
     if n == 0:
         return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
-    if max_num is None or max_num < 0:
-        max_num = ops._lib.IA_MAX_PER_IMG
+    cap = ops._lib.IA_MAX_PER_IMG
+    if n > ops._lib.IA_MAX_CANDIDATES:
+        raise ValueError('multiclass_nms: %d boxes, the HIP path handles at most %d per image'
+                         % (n, ops._lib.IA_MAX_CANDIDATES))
+    drop_last = max_num is None or max_num < 0
+    if drop_last:
+        # reference quirk (bbox_nms.py:52-56): `shape[0] > -1` is always true, so the survivors
+        # are sorted by score and `inds[:-1]` drops the lowest one.  Emulated while the survivor
+        # count fits the library's per-image output buffer.
+        max_num = cap
+    elif max_num > cap:
+        raise ValueError('multiclass_nms: max_num=%d exceeds the per-image output capacity %d'
+                         % (max_num, cap))
     Cn = multi_scores.shape[1] - 1
     Rs = (n + 63) // 64 * 64
     scores_t = multi_bboxes.new_zeros((1, Cn, Rs), dtype=torch.float32)
@@ -86,4 +97,9 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
     else:
         out = ops.multiclass_nms(boxes, scores_t, n, score_thr, cfg['iou_thr'], int(max_num))
     k = int(out[3][0].item())
+    if drop_last:
+        if k >= cap:
+            raise ValueError('multiclass_nms(max_num=-1): %d or more survivors, beyond the '
+                             'per-image output capacity; pass an explicit max_num' % cap)
+        k = max(k - 1, 0)
     return out[0][0, :k], out[1][0, :k].to(torch.long)

@@ -92,6 +92,12 @@ def train_step(model, optimizer, img, img_meta, gt_bboxes, gt_labels, grad_clip=
     Returns the log_vars of parse_losses as python floats (one host sync at the end)."""
     losses = model(img, img_meta, return_loss=True, gt_bboxes=gt_bboxes, gt_labels=gt_labels)
     if losses is None:                       # an image without valid anchors (reference :362-363)
+        if (allreduce or hasattr(model, 'reducer')) and dist.is_available() \
+                and dist.is_initialized() and dist.get_world_size() > 1:
+            # the other ranks are about to enter the gradient all-reduce: returning here would
+            # leave them blocked in the collective.  Fail loudly instead of hanging the job.
+            raise RuntimeError('rank %d: head.loss returned None (an image without valid '
+                               'anchors) in a distributed step' % dist.get_rank())
         return None
     loss, log_vars = parse_losses(losses)
     optimizer.zero_grad()
@@ -102,4 +108,5 @@ def train_step(model, optimizer, img, img_meta, gt_bboxes, gt_labels, grad_clip=
         clip_grad_norm_([p for p in model.parameters() if p.requires_grad and p.grad is not None],
                         **grad_clip)
     optimizer.step()
-    return OrderedDict((k, float(v.detach())) for k, v in log_vars.items())
+    vals = torch.stack([v.detach().reshape(()).float() for v in log_vars.values()]).tolist()
+    return OrderedDict(zip(log_vars.keys(), vals))     # the one host sync of the iteration

@@ -435,6 +435,148 @@ def gen_losses_balanced():
     save('losses_balanced', **out)
 
 
+# ---------------------------------------------------------------- end to end (config 1; I12, I13, f.1)
+E2E_CASES = (
+    # name, weight seed, image seed, pad h, pad w, img h, img w, scale_factor
+    ('small', 77, 5, 256, 320, 250, 317, 1.25),
+    ('full', 77, 6, 800, 1344, 800, 1333, 1.0),
+)
+COCO_CAT_IDS = [i for i in range(1, 91) if i not in (12, 26, 29, 30, 45, 66, 68, 69, 71, 83)]
+
+
+class _FakeCoco(object):
+    """what det2json reads from a CocoDataset (coco_utils.py:103-113): len, img_ids, cat_ids"""
+
+    def __init__(self, img_ids):
+        self.img_ids, self.cat_ids = list(img_ids), list(COCO_CAT_IDS)
+
+    def __len__(self):
+        return len(self.img_ids)
+
+
+def gen_e2e():
+    """the reference's own test-time call (tools/test.py:25 -> base.py:62-123 ->
+    single_stage.py:64-96) on a whole R-50 detector with the deterministic 'trained-like'
+    weights of synth.e2e_fill_state: image -> per-class result arrays."""
+    import json
+    from mmdet.models import build_detector
+    from mmdet.core.evaluation import coco_utils
+    rcfg = ref_shim.load_config(ref_shim.REF + '/configs/iou_aware_single_stage_detector/'
+                                'iou_aware_retinanet_r50_fpn_1x_4gpu.py')
+    rcfg.model['pretrained'] = None
+    assert len(COCO_CAT_IDS) == 80
+    for name, wseed, iseed, ph, pw, ih, iw, sf in E2E_CASES:
+        torch.manual_seed(0)
+        ref = build_detector(rcfg.model, train_cfg=rcfg.train_cfg, test_cfg=rcfg.test_cfg).eval()
+        with torch.no_grad():
+            synth.e2e_fill_state(ref.state_dict(), wseed)
+        img = synth.e2e_image(iseed, 1, ph, pw, ih, iw)
+        ori = (int(round(ih / sf)), int(round(iw / sf)), 3)
+        meta = dict(ori_shape=ori, img_shape=(ih, iw, 3), pad_shape=(ph, pw, 3), scale_factor=sf,
+                    flip=False)
+        g, l = synth.e2e_gts(iseed + 100, ih, iw)
+        x = torch.from_numpy(img)
+        # head outputs, for the conv-level tolerance check on the GPU
+        with torch.no_grad():
+            cls, reg, iou = ref.bbox_head(ref.extract_feat(x))
+        out = dict(weight_seed=wseed, image_seed=iseed, img=np.array([ih, iw, ph, pw]),
+                   scale_factor=np.float32(sf), ori_shape=np.array(ori),
+                   gt_bboxes=g, gt_labels=l, img_checksum=synth.checksum([img]),
+                   weight_checksum=synth.checksum(
+                       [v.numpy() for k, v in sorted(ref.state_dict().items())]))
+        rs = np.random.RandomState(1000 + iseed)
+        for nm, ts in (('cls', cls), ('reg', reg), ('iou', iou)):
+            for lv, t in enumerate(ts):
+                a = t.numpy().reshape(-1)
+                idx = rs.choice(a.size, min(a.size, 2048), replace=False).astype(np.int64)
+                out['%s_idx_%d' % (nm, lv)] = idx
+                out['%s_val_%d' % (nm, lv)] = a[idx]
+                out['%s_rms_%d' % (nm, lv)] = np.float64(np.sqrt((a.astype(np.float64) ** 2).mean()))
+        import mmdet.models.detectors.single_stage as ref_ss
+        b2r, b2r_in = ref_ss.bbox2result, []
+        ref_ss.bbox2result = lambda d, lb, n: (b2r_in.append((d.clone(), lb.clone())), b2r(d, lb, n))[1]
+        with Capture() as cap, torch.no_grad():
+            result = ref(return_loss=False, rescale=True, img=[x], img_meta=[[meta]],
+                         gt_bboxes=[[torch.from_numpy(g)]], gt_labels=[[torch.from_numpy(l)]])
+        ref_ss.bbox2result = b2r
+        out['det_bboxes'], out['det_labels'] = b2r_in[0][0].numpy(), b2r_in[0][1].numpy()
+        assert isinstance(result, list) and len(result) == 80
+        mb, ms = cap.mlvl[0]
+        # candidate indices per level, in the reference's order
+        topk_inds, ti, margins = [], 0, []
+        for lv in range(5):
+            Nl = cls[lv].shape[2] * cls[lv].shape[3] * synth.A
+            if Nl > 1000:
+                ms_l, idx = cap.topk[ti]
+                ti += 1
+                topk_inds.append(idx.numpy().astype(np.int32))
+                srt = ms_l.sort(descending=True).values[:1001].double()
+                margins.append(float(((srt[:-1] - srt[1:]) / srt[:-1]).min()))
+                out['topk_cut_margin_%d' % lv] = np.float64((srt[999] - srt[1000]) / srt[999])
+            else:
+                topk_inds.append(np.arange(Nl, dtype=np.int32))
+        out['topk_inds'] = np.concatenate(topk_inds)
+        out['topk_margin'] = np.array(margins)
+        # all survivors of the 80 NMS problems, ranked like multiclass_nms ranks them (bbox_nms.py:52-56)
+        surv = []
+        ci = 0
+        for c in range(80):
+            mask = ms[:, c + 1] > 0.05
+            if not mask.any():
+                continue
+            dets_c, inds = cap.nms_calls[ci]
+            ci += 1
+            rows = torch.nonzero(mask).squeeze(1)[inds]
+            surv += [(float(dets_c[i, 4]), c, int(r)) for i, r in zip(inds.tolist(), rows.tolist())]
+        surv.sort(key=lambda t: -t[0])
+        out['num_survivors'] = len(surv)
+        out['into_nms'] = int((ms[:, 1:] > 0.05).sum())
+        sc = np.array([s[0] for s in surv[:101]], np.float64)
+        out['det_score_gaps'] = (sc[:-1] - sc[1:]) / sc[:-1]          # relative gaps of the ranking
+        out['det_rows'] = np.array([s[2] for s in surv[:100]], np.int32)
+        out['det_classes'] = np.array([s[1] for s in surv[:100]], np.int32)
+        out['result_counts'] = np.array([r.shape[0] for r in result], np.int32)
+        out['result_cat'] = np.concatenate(result, 0).astype(np.float32)
+        assert all(r.dtype == np.float32 and r.shape[1] == 5 for r in result)
+        js = coco_utils.det2json(_FakeCoco([397133]), [result])
+        out['coco_json'] = np.array(json.dumps(js))
+        out['coco_cat_ids'] = np.array(COCO_CAT_IDS)
+        print('e2e', name, 'dets', int(out['result_counts'].sum()), 'survivors', len(surv),
+              'into-nms', out['into_nms'], 'topk margins', margins,
+              'min det gap %.2e' % out['det_score_gaps'].min(),
+              'cut gap %.2e' % out['det_score_gaps'][-1])
+        save('e2e_' + name, **out)
+
+
+# ---------------------------------------------------------------- T4 pin
+def gen_focal_op():
+    """SigmoidFocalLoss op (T4): the CUDA kernel has no CPU twin in the reference, but for integer
+    targets and unit weights py_sigmoid_focal_loss (losses.py:226-247) -- the function the
+    IoU-aware head really uses -- computes the same quantity on a one-hot target.  Stored: the
+    elementwise loss and its autograd gradient under a random upstream gradient."""
+    rs = np.random.RandomState(41)
+    N, C = 131, 80
+    x = (rs.standard_normal((N, C)) * 3.0 - 2.0).astype(np.float32)
+    x[0, :8] = [-30, -12, -1e-3, 0.0, 1e-3, 12, 30, 80]           # extremes
+    t = rs.randint(0, C + 1, N).astype(np.int64)                   # 0 = background
+    t[:8] = [1, 2, 3, 4, 5, 6, 7, 8]
+    up = rs.uniform(0.1, 2.0, (N, C)).astype(np.float32)
+    out = dict(seed=41, logits=x, targets=t, upstream=up)
+    for gamma, alpha in ((2.0, 0.25), (1.5, 0.4), (0.0, 0.5)):
+        tx = torch.from_numpy(x).clone().requires_grad_(True)
+        onehot = torch.zeros(N, C)
+        pos = torch.nonzero(torch.from_numpy(t) >= 1).squeeze(1)
+        onehot[pos, torch.from_numpy(t)[pos] - 1] = 1
+        loss = ref_losses.py_sigmoid_focal_loss(tx, onehot, torch.ones(N, C), gamma=gamma,
+                                                alpha=alpha, reduction='none')
+        (loss * torch.from_numpy(up)).sum().backward()
+        tag = 'g%g_a%g' % (gamma, alpha)
+        out['loss_' + tag] = loss.detach().numpy()
+        out['grad_' + tag] = tx.grad.numpy()
+    out['params'] = np.array([[2.0, 0.25], [1.5, 0.4], [0.0, 0.5]], np.float32)
+    save('focal_op', **out)
+
+
 # ---------------------------------------------------------------- model structure (B1, I3)
 def gen_model():
     """parameter names / shapes of the four reference configs (+ the 64x4d backbone of BASELINE
@@ -457,6 +599,6 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op']
     for w in which:
         globals()['gen_' + w]()

@@ -87,3 +87,69 @@ def train_targets(seed, batch, pad_h, pad_w, max_gt=8):
         gts.append(b.astype(np.float32))
         labels.append(rs.randint(1, C + 1, g).astype(np.int64))
     return gts, labels
+
+
+# ------------------------------------------------------------------ end-to-end fixtures
+# "Trained-like" deterministic weights for the image -> detections fixtures
+# (tests/golden/e2e_*.npz).  The reference's own random init gives degenerate, heavily tied
+# scores; these weights keep activations at unit scale through the network and
+# give head logits with the spread of set 'A' (tie-free, a few hundred boxes per class), so
+# that a 1e-5 difference between two convolution algorithms cannot flip a selection.  The
+# scheme depends on parameter NAMES and SHAPES only, which are identical in the reference and
+# in this build (tests/golden/state_dict_keys.json), so both sides get bit-identical weights.
+E2E_HEAD_GAIN = dict(retina_cls=1.4, retina_reg=0.45, retina_iou=1.6)   # -> std 2 / 0.5 / 1.5 on P3
+E2E_CLS_BIAS = -6.0
+E2E_LATERAL_GAIN = 0.125
+
+
+def e2e_fill_state(state, seed):
+    """fill a detector state dict (name -> torch tensor, modified in place) from `seed`."""
+    import torch
+    rs = np.random.RandomState(seed)
+    for key in sorted(state.keys()):
+        t = state[key]
+        if key.endswith('num_batches_tracked'):
+            continue
+        shape = tuple(t.shape)
+        leaf = key.split('.')[-1]
+        if key.endswith('running_mean'):
+            v = rs.standard_normal(shape) * 0.05
+        elif key.endswith('running_var'):
+            v = rs.uniform(0.8, 1.2, shape)
+        elif t.dim() == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = np.sqrt(2.0 / fan_in)                       # keeps the scale through a ReLU
+            if key.startswith('neck.'):
+                gain = np.sqrt(1.0 / fan_in)                   # FPN convs have no activation
+                if '.lateral_convs.' in key or '.fpn_convs.3.' in key:
+                    gain *= E2E_LATERAL_GAIN                   # brings C3..C5 (P6 reads C5) back to unit scale
+            for name, g in E2E_HEAD_GAIN.items():
+                if ('.%s.' % name) in key:
+                    gain = g * np.sqrt(1.0 / fan_in)
+            v = rs.standard_normal(shape) * gain
+        elif key.startswith('backbone.') and leaf == 'weight':   # BatchNorm scale
+            v = rs.uniform(0.8, 1.2, shape)
+            if '.bn3.' in key:
+                v = v * 0.25                                   # residual branch: no blow-up
+        elif leaf == 'bias':
+            v = rs.standard_normal(shape) * (0.05 if key.startswith('backbone.') else 0.02)
+            if '.retina_cls.' in key:
+                v = E2E_CLS_BIAS + rs.standard_normal(shape) * 0.5
+        else:
+            raise KeyError('e2e_fill_state: no rule for %s %s' % (key, shape))
+        t.copy_(torch.from_numpy(np.asarray(v, np.float32)))
+
+
+def e2e_image(seed, batch, pad_h, pad_w, img_h, img_w):
+    """N(0,1) image, zero in the padding like ImageTransform's pad (transforms.py:44-46)."""
+    rs = np.random.RandomState(seed)
+    img = rs.standard_normal((batch, 3, pad_h, pad_w)).astype(np.float32)
+    img[:, :, img_h:, :] = 0
+    img[:, :, :, img_w:] = 0
+    return img
+
+
+def e2e_gts(seed, img_h, img_w):
+    """gt boxes / labels for the test-time call (dead inputs in the reference, :517-524)."""
+    g, l = train_targets(seed, 1, img_h, img_w, max_gt=4)
+    return g[0], l[0]

@@ -36,6 +36,31 @@ def test_base_and_grid_anchors(oracle_lib, golden_dir):
                           g['base_16_rpn'])
 
 
+def test_host_anchor_generator_matches_reference(golden_dir):
+    """iouaware/anchors.py (the generator the head really uses: head.geometry -> ia_head_geom)
+    directly against the reference-generated anchors.npz (I1, I2)."""
+    from iouaware.anchors import AnchorGenerator
+    g = np.load(os.path.join(golden_dir, 'anchors.npz'))
+    scales = np.array([2 ** (i / 3) for i in range(3)]) * 4       # iou_aware_retina_head.py:81-83
+    for s in synth.STRIDES:
+        gen = AnchorGenerator(s, scales, [0.5, 1.0, 2.0])
+        assert gen.base_anchors.dtype.is_floating_point
+        assert np.array_equal(gen.base_anchors.numpy(), g['base_%d' % s])
+    assert np.array_equal(AnchorGenerator(8, scales, [0.5, 1.0, 2.0]).grid_anchors((5, 7), 8).numpy(),
+                          g['grid_8_5x7'])
+    assert np.array_equal(AnchorGenerator(32, scales, [0.5, 1.0, 2.0]).grid_anchors((3, 4), 32).numpy(),
+                          g['grid_32_3x4'])
+    assert np.array_equal(AnchorGenerator(16, [8, 16, 32], [0.5, 1.0, 2.0]).base_anchors.numpy(),
+                          g['base_16_rpn'])
+    # and through the head: the geometry handed to the HIP kernels carries these base anchors
+    import iouaware
+    from iouaware.config import ConfigDict
+    from test_host_model import model_cfg
+    head = iouaware.build_head(ConfigDict(model_cfg()['bbox_head']))
+    for i, s in enumerate(synth.STRIDES):
+        assert np.array_equal(head.anchor_generators[i].base_anchors.numpy(), g['base_%d' % s])
+
+
 def test_delta2bbox(oracle_lib, golden_dir):
     d = np.load(os.path.join(golden_dir, 'delta2bbox.npz'))
     assert close(oracle_lib.delta2bbox(d['rois'], d['deltas'], max_shape=(800, 1333)),

@@ -82,6 +82,23 @@ def test_focal_op_formula_against_float64(oracle_lib):
     assert np.abs(ggot - gwant).max() <= 1e-5 * max(1.0, np.abs(gwant).max())
 
 
+def test_focal_op_pinned_on_reference_py_focal_loss(oracle_lib, golden_dir):
+    """T4 pin: for integer targets and unit weights the reference's own CPU
+    py_sigmoid_focal_loss (losses.py:226-247) on the one-hot target computes what the CUDA op
+    computes; loss and autograd gradient captured by make_golden.py focal_op."""
+    f = np.load(os.path.join(golden_dir, 'focal_op.npz'))
+    x, t, up = f['logits'], f['targets'], f['upstream']
+    for gamma, alpha in f['params']:
+        tag = 'g%g_a%g' % (gamma, alpha)
+        got = oracle_lib.focal_loss_op(x, t, float(gamma), float(alpha))
+        want = f['loss_' + tag]
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), tag
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), tag
+        ggot = oracle_lib.focal_loss_op(x, t, float(gamma), float(alpha), up)
+        gwant = f['grad_' + tag]
+        assert np.abs(ggot - gwant).max() <= 1e-5 * max(1.0, np.abs(gwant).max()), tag
+
+
 def test_iou_balanced_losses_match_reference(oracle_lib, fx, golden_dir):
     """IOUbalancedSigmoidFocalLoss(eta=1.5) + IoUbalancedSmoothL1Loss(delta=1.5,
     loss_weight=3.049) through the reference head (tests/golden/losses_balanced.npz); targets are
