@@ -115,7 +115,7 @@ def _print_report():
             print('  ' + line)
         out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
         if os.path.isdir(out):
-            with open(os.path.join(out, 'e2e_parity_report.txt'), 'a') as fh:
+            with open(os.path.join(out, 'e2e_parity_report.txt'), 'w') as fh:
                 fh.write('\n'.join(_REPORT) + '\n')
 
 
@@ -208,8 +208,10 @@ def test_reference_call_signature_variants(golden_dir):
                gt_bboxes=[[torch.zeros(0, 4).cuda()]], gt_labels=[[torch.zeros(0).long().cuda()]])
         # rescale=False keeps the boxes in the resized image's frame
         r2 = m(return_loss=False, rescale=False, img=[x], img_meta=[[meta]])
+    # (two forwards of the MIOpen module path are not bit-identical: find-mode may pick another
+    # algorithm for the second call -- hence closeness, not equality)
     for a, b in zip(r0, r1):
-        assert np.array_equal(a, b)
+        assert a.shape == b.shape and G.close(a, b, TOL)
     sf = float(f['scale_factor'])
     cat0, cat2 = np.concatenate(r0), np.concatenate(r2)
     assert cat0.shape == cat2.shape and np.allclose(cat0[:, :4] * sf, cat2[:, :4], rtol=1e-6, atol=1e-4)
@@ -218,7 +220,7 @@ def test_reference_call_signature_variants(golden_dir):
         two = m(return_loss=False, rescale=True, img=[torch.cat([x, x])], img_meta=[[meta, meta]])
     assert len(two) == 2 and all(len(r) == 80 for r in two)
     for a, b in zip(two[0], r0):
-        assert np.array_equal(a, b)
+        assert a.shape == b.shape and G.close(a, b, TOL)
 
 
 def test_fused_copies_follow_the_parameters(golden_dir):
