@@ -334,6 +334,61 @@ int ia_anchor_targets(const ia_head_geom *g, const float *gt_boxes, const int64_
                       uint32_t *gt_max_scratch, int64_t *labels, float *label_weights,
                       float *bbox_targets, float *bbox_weights, int32_t *counts, void *stream);
 
+/* The same assignment with the gt boxes where the data loader left them: HOST arrays of
+ * per-image DEVICE pointers gt_boxes[b] (num_gt[b],4) fp32 / gt_labels[b] (num_gt[b]) int64 (or
+ * gt_labels == NULL), host num_gt[b] in 1..512 and host valid_hw (B,L,2).  Pointers and sizes
+ * travel in the kernel arguments: no padded staging tensors, no host-to-device copies.
+ * batch <= IA_MAX_TARGET_BATCH.                                                    */
+#define IA_MAX_TARGET_BATCH 16
+int ia_anchor_targets_ptrs(const ia_head_geom *g, const float *const *gt_boxes,
+                           const int64_t *const *gt_labels, const int32_t *num_gt, int batch,
+                           const int32_t *valid_hw, float pos_iou_thr, float neg_iou_thr,
+                           float min_pos_iou, float pos_weight, uint32_t *gt_max_scratch,
+                           int64_t *labels, float *label_weights, float *bbox_targets,
+                           float *bbox_weights, int32_t *counts, void *stream);
+
+/* ------------------------------------------------------------------ IoUawareRetinaHead.loss, all levels
+ * One call for the forward and one for the backward of the three losses of every pyramid level
+ * (iou_aware_retina_head.py:221-313 x L, :315-387): FocalLoss(gamma = 2) on the class logits,
+ * SmoothL1Loss on the deltas, IoU target + BCE on the IoU logits; 4 + 2 kernel launches.
+ * Head outputs NCHW (g->layout == IA_LAYOUT_NCHW), per-level targets as ia_anchor_targets
+ * writes them.                                                                       */
+typedef struct ia_head_targets {
+    const int64_t *labels[IA_MAX_LEVELS];        /* (B, N_l) int64 in 0..C                 */
+    const float *label_weights[IA_MAX_LEVELS];   /* (B, N_l)                               */
+    const float *bbox_targets[IA_MAX_LEVELS];    /* (B, N_l, 4)                            */
+    const float *bbox_weights[IA_MAX_LEVELS];    /* (B, N_l, 4)                            */
+    /* avg_factor (num_total_samples), first non-NULL / positive of:                       */
+    const int32_t *counts;                       /* (B,2) of ia_anchor_targets: sum_b max(pos_b,1) */
+    const float *avg_factor_dev;                 /* device scalar                          */
+    float avg_factor;                            /* host value                             */
+} ia_head_targets;
+
+typedef struct ia_head_loss_cfg {
+    float gamma, alpha, loss_weight_cls;         /* FocalLoss; gamma must be 2             */
+    float beta, loss_weight_bbox;                /* SmoothL1Loss                           */
+    int32_t attach_iou_target;                   /* gradient through the IoU target (reference: yes) */
+    int32_t exact_large_logits;                  /* class logits > 60: the loss VALUE of such a negative
+                                                    element saturates at 60 unless this is set (one more
+                                                    pass over the logits); gradients are exact either way */
+} ia_head_loss_cfg;
+
+/* workspace (256-byte aligned, ia_head_loss_workspace_bytes): the fp64 partial sums and an
+ * anchor-major copy of labels / label_weights that the forward call writes and the backward
+ * call reads -- keep it alive and untouched between the two.
+ * result: (3L + 4) fp32 = loss_cls[L] | loss_bbox[L] | losses_iou[L] | their sums over the
+ * levels [3] | avg_factor -- each loss = loss_weight * (sum / avg_factor).              */
+size_t ia_head_loss_workspace_bytes(const ia_head_geom *g, int batch);
+int ia_head_loss_fwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, int batch,
+                     const ia_head_targets *t, const ia_head_loss_cfg *cfg, void *workspace,
+                     size_t workspace_bytes, float *result, void *stream);
+/* grad_result: (3L + 3) fp32 upstream gradients in result's order (per-level entries and the
+ * three totals add up); grads: fp32 NCHW tensors shaped like the head outputs.          */
+int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, int batch,
+                     const ia_head_targets *t, const ia_head_loss_cfg *cfg, const void *workspace,
+                     const float *result, const float *grad_result, const ia_level_ptrs *grads,
+                     void *stream);
+
 /* mmdet.ops.sigmoid_focal_loss: sigmoid_focal_loss_cuda.forward / .backward
  * (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-63,65-105;
  * binding sigmoid_focal_loss.cpp:17-43).  logits (N,C) fp32, targets (N) int64,

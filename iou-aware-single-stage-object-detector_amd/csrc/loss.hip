@@ -14,52 +14,9 @@
 // so every class-plane access is a contiguous 1 KiB segment, and the label /
 // weight of an anchor are read once for all C classes.  Sums are reduced in
 // fp64 (wave shuffle -> LDS -> one fp64 atomic per workgroup).
-#include "ia_internal.hpp"
-#include "ia_math.hpp"
-#include "ia_block.hpp"
+#include "ia_loss.hpp"
 
 namespace ia {
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
-}
-
-// every thread of the workgroup calls; one atomic per workgroup
-__device__ __forceinline__ void block_sum_to(double v, double *dst, double *lds /* >= 16 */)
-{
-    const uint32_t tid = threadIdx.y * blockDim.x + threadIdx.x;
-    const uint32_t nw = (blockDim.x * blockDim.y + kWave - 1) / kWave;
-    v = wave_sum(v);
-    if ((tid & (kWave - 1)) == 0) lds[tid / kWave] = v;
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (uint32_t w = 0; w < nw; ++w) s += lds[w];
-        atomicAdd(dst + (blockIdx.x & (IA_LOSS_SLOTS - 1)), s);   // IA_LOSS_SLOTS partial sums
-    }
-}
-
-// upstream gradient: host scalar times an optional device scalar (autograd's
-// grad_output stays on the device: no host synchronisation in backward)
-__device__ __forceinline__ float eff_scale(float host, const float *dev)
-{
-    return dev ? host * dev[0] : host;
-}
-
-// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp).  The loss kernels
-// stream 80 logits per anchor and must stay HBM-bound: the bit-reproducible software
-// exp/log/divide of ia_math.hpp (needed on the inference path for index parity) costs ~200
-// VALU slots per element here, 3x the budget of an 8 TB/s stream.  Losses have no index
-// outputs; their parity bar is the north star's 1e-4, checked against the oracle and the
-// reference's autograd.
-namespace fastm {
-__device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-__device__ __forceinline__ float log_(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
-__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-}  // namespace fastm
 
 // ------------------------------------------------------------------ focal
 struct FocalArgs {
@@ -357,36 +314,6 @@ static int launch_smooth(bool bwd, const void *pred, int dtype, const float *tar
 }
 
 // ------------------------------------------------------------------ IoU target + BCE
-struct Dec { float x1, y1, x2, y2, gw, gh, pw, ph; bool win, hin; };
-
-__device__ __forceinline__ Dec decode_free(const float (&anc)[4], const float (&d)[4],
-                                           const float *means, const float *stds)
-{
-    const float max_ratio = 4.135166556742356f;
-    Dec r;
-    float dx = d[0] * stds[0] + means[0];
-    float dy = d[1] * stds[1] + means[1];
-    float dw = d[2] * stds[2] + means[2];
-    float dh = d[3] * stds[3] + means[3];
-    r.win = (dw >= -max_ratio) && (dw <= max_ratio);
-    r.hin = (dh >= -max_ratio) && (dh <= max_ratio);
-    dw = (dw < -max_ratio) ? -max_ratio : dw;  dw = (dw > max_ratio) ? max_ratio : dw;
-    dh = (dh < -max_ratio) ? -max_ratio : dh;  dh = (dh > max_ratio) ? max_ratio : dh;
-    float px = (anc[0] + anc[2]) * 0.5f;
-    float py = (anc[1] + anc[3]) * 0.5f;
-    r.pw = (anc[2] - anc[0]) + 1.0f;
-    r.ph = (anc[3] - anc[1]) + 1.0f;
-    r.gw = r.pw * expf_(dw);
-    r.gh = r.ph * expf_(dh);
-    float gx = px + r.pw * dx;
-    float gy = py + r.ph * dy;
-    r.x1 = (gx - r.gw * 0.5f) + 0.5f;
-    r.y1 = (gy - r.gh * 0.5f) + 0.5f;
-    r.x2 = (gx + r.gw * 0.5f) - 0.5f;
-    r.y2 = (gy + r.gh * 0.5f) - 0.5f;
-    return r;
-}
-
 struct IouBceArgs {
     const void *bbox_pred;
     const void *iou_pred;
@@ -429,19 +356,8 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
                              load_f32<T>(bp + (size_t)2 * HW), load_f32<T>(bp + (size_t)3 * HW)};
         const float4 tq = reinterpret_cast<const float4 *>(a.bbox_targets)[n];
         const float dt[4] = {tq.x, tq.y, tq.z, tq.w};
-        Dec pb = decode_free(anc, dp, a.means, a.stds);
-        Dec tb = decode_free(anc, dt, a.means, a.stds);
-        float ltx = (tb.x1 < pb.x1) ? pb.x1 : tb.x1;
-        float lty = (tb.y1 < pb.y1) ? pb.y1 : tb.y1;
-        float rbx = (pb.x2 < tb.x2) ? pb.x2 : tb.x2;
-        float rby = (pb.y2 < tb.y2) ? pb.y2 : tb.y2;
-        float w0 = (rbx - ltx) + 1.0f, h0 = (rby - lty) + 1.0f;
-        float w = (w0 < 0.0f) ? 0.0f : w0, h = (h0 < 0.0f) ? 0.0f : h0;
-        float ov = w * h;
-        float a1 = ((tb.x2 - tb.x1) + 1.0f) * ((tb.y2 - tb.y1) + 1.0f);
-        float a2 = ((pb.x2 - pb.x1) + 1.0f) * ((pb.y2 - pb.y1) + 1.0f);
-        float un = (a1 + a2) - ov;
-        float t = ov / un;
+        const IouElem q = iou_target_elem(anc, dp, dt, a.means, a.stds);
+        const float t = q.t;
         float xl = load_f32<T>(static_cast<const T *>(a.iou_pred) + e);
         float wt = a.bbox_weights[4 * n];
         if (!BWD) {
@@ -450,28 +366,13 @@ __global__ void __launch_bounds__(256) k_iou_bce(IouBceArgs a)
         } else {
             if (a.grad_iou_pred) a.grad_iou_pred[e] = ((sigmoidf_(xl) - t) * wt) * gs;
             if (a.grad_bbox_pred) {
-                float gt = ((-xl) * wt) * gs;
-                float inv_un = 1.0f / un;
-                float g_ov = gt * ((un + ov) * inv_un) * inv_un;
-                float g_a2 = gt * (-(ov * inv_un) * inv_un);
-                float g_w = (w0 >= 0.0f) ? g_ov * h : 0.0f;
-                float g_h = (h0 >= 0.0f) ? g_ov * w : 0.0f;
-                float pw2 = (pb.x2 - pb.x1) + 1.0f, ph2 = (pb.y2 - pb.y1) + 1.0f;
-                float gx1 = -g_a2 * ph2, gx2 = g_a2 * ph2;
-                float gy1 = -g_a2 * pw2, gy2 = g_a2 * pw2;
-                float sx1 = (pb.x1 > tb.x1) ? 1.0f : ((pb.x1 == tb.x1) ? 0.5f : 0.0f);
-                float sy1 = (pb.y1 > tb.y1) ? 1.0f : ((pb.y1 == tb.y1) ? 0.5f : 0.0f);
-                float sx2 = (pb.x2 < tb.x2) ? 1.0f : ((pb.x2 == tb.x2) ? 0.5f : 0.0f);
-                float sy2 = (pb.y2 < tb.y2) ? 1.0f : ((pb.y2 == tb.y2) ? 0.5f : 0.0f);
-                gx1 = gx1 - g_w * sx1;  gx2 = gx2 + g_w * sx2;
-                gy1 = gy1 - g_h * sy1;  gy2 = gy2 + g_h * sy2;
-                float g_gx = gx1 + gx2, g_gy = gy1 + gy2;
-                float g_gw = (gx2 - gx1) * 0.5f, g_gh = (gy2 - gy1) * 0.5f;
+                float gv[4];
+                iou_bce_box_grad(q, xl, wt, gs, a.stds, gv);
                 float *go = a.grad_bbox_pred + ba * 4 * HW + p;
-                go[0] = (g_gx * pb.pw) * a.stds[0];
-                go[(size_t)HW] = (g_gy * pb.ph) * a.stds[1];
-                go[(size_t)2 * HW] = pb.win ? (g_gw * pb.gw) * a.stds[2] : 0.0f;
-                go[(size_t)3 * HW] = pb.hin ? (g_gh * pb.gh) * a.stds[3] : 0.0f;
+                go[0] = gv[0];
+                go[(size_t)HW] = gv[1];
+                go[(size_t)2 * HW] = gv[2];
+                go[(size_t)3 * HW] = gv[3];
             }
         }
     }

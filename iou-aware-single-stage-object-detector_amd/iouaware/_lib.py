@@ -15,6 +15,7 @@ IA_MAX_PER_IMG = 1024
 IA_F32, IA_BF16 = 0, 1
 IA_LAYOUT_NCHW, IA_LAYOUT_NHWC = 0, 1
 IA_LOSS_SLOTS = 64
+IA_MAX_TARGET_BATCH = 16
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'csrc')
 SO_PATH = os.path.abspath(os.path.join(_CSRC, 'libiouaware_hip.so'))
@@ -32,6 +33,19 @@ class HeadGeom(C.Structure):
 class LevelPtrs(C.Structure):
     _fields_ = [('cls', C.c_void_p * IA_MAX_LEVELS), ('reg', C.c_void_p * IA_MAX_LEVELS),
                 ('iou', C.c_void_p * IA_MAX_LEVELS)]
+
+
+class HeadTargets(C.Structure):
+    _fields_ = [('labels', C.c_void_p * IA_MAX_LEVELS), ('label_weights', C.c_void_p * IA_MAX_LEVELS),
+                ('bbox_targets', C.c_void_p * IA_MAX_LEVELS),
+                ('bbox_weights', C.c_void_p * IA_MAX_LEVELS), ('counts', C.c_void_p),
+                ('avg_factor_dev', C.c_void_p), ('avg_factor', C.c_float)]
+
+
+class HeadLossCfg(C.Structure):
+    _fields_ = [('gamma', C.c_float), ('alpha', C.c_float), ('loss_weight_cls', C.c_float),
+                ('beta', C.c_float), ('loss_weight_bbox', C.c_float),
+                ('attach_iou_target', C.c_int32), ('exact_large_logits', C.c_int32)]
 
 
 class ImageDesc(C.Structure):
@@ -102,6 +116,14 @@ SIGNATURES = {
     'ia_iou_bce_bwd': (_i, [_G, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     'ia_anchor_targets': (_i, [_G, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp]),
+    'ia_anchor_targets_ptrs': (_i, [_G, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _f, _f, _f, _f,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ia_head_loss_workspace_bytes': (_sz, [_G, _i]),
+    'ia_head_loss_fwd': (_i, [_G, _P, _i, _i, C.POINTER(HeadTargets), C.POINTER(HeadLossCfg), _vp,
+                              _sz, _vp, _vp]),
+    'ia_head_loss_bwd': (_i, [_G, _P, _i, _i, C.POINTER(HeadTargets), C.POINTER(HeadLossCfg), _vp,
+                              _vp, _vp, _P, _vp]),
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_channel_affine_act': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),

@@ -240,6 +240,15 @@ class IoUawareRetinaHead(AnchorHead):
                 and all(g.shape[0] >= 1 for g in gt_bboxes)
                 and max(g.shape[0] for g in gt_bboxes) <= 512)
 
+    fuse_levels = True                    # all-levels loss kernels when the configuration allows
+
+    def _fused_loss_ok(self, cls_scores):
+        from .losses import FocalLoss, SmoothL1Loss
+        return (self.fuse_levels and type(self.loss_cls) is FocalLoss
+                and type(self.loss_bbox) is SmoothL1Loss and float(self.loss_cls.gamma) == 2.0
+                and self.use_sigmoid_cls and not self.sampling and cls_scores[0].is_cuda
+                and cls_scores[0].dtype in (torch.float32, torch.bfloat16))
+
     def loss(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, gt_labels, img_metas, cfg,
              gt_bboxes_ignore=None):
         """-> dict(loss_cls, loss_bbox, losses_iou), each a list of per-level (1,) tensors, or
@@ -258,8 +267,11 @@ class IoUawareRetinaHead(AnchorHead):
                 geom, gt_bboxes, gt_labels, [m['pad_shape'] for m in img_metas],
                 acfg['pos_iou_thr'], acfg['neg_iou_thr'], acfg.get('min_pos_iou', .0),
                 cfg.pos_weight)
-            num_total_samples = counts[:, 0].clamp(min=1).sum().to(torch.float32)
             level_anchors = [None] * len(featmap_sizes)
+            if self._fused_loss_ok(cls_scores):
+                num_total_samples = counts             # reduced inside the finalize kernel
+            else:
+                num_total_samples = counts[:, 0].clamp(min=1).sum().to(torch.float32)
         else:
             anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
             label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
@@ -272,6 +284,19 @@ class IoUawareRetinaHead(AnchorHead):
                 return None
             labels, label_w, bbox_t, bbox_w, n_pos, n_neg, level_anchors = targets
             num_total_samples = n_pos + n_neg if self.sampling else n_pos
+            counts = None
+        if self._fused_loss_ok(cls_scores):
+            # all levels, all three losses: one autograd node, 3 + 2 kernel launches
+            # (csrc/headloss.hip); the per-level path below stays for the other loss types
+            on_dev = level_anchors[0] is None          # targets came from the HIP assigner
+            return ops.head_loss(
+                geom, cls_scores, bbox_preds, iou_preds, labels, label_w, bbox_t, bbox_w,
+                counts=counts if on_dev else None,
+                avg_factor=None if on_dev else num_total_samples,
+                gamma=self.loss_cls.gamma, alpha=self.loss_cls.alpha,
+                loss_weight_cls=self.loss_cls.loss_weight, beta=self.loss_bbox.beta,
+                loss_weight_bbox=self.loss_bbox.loss_weight,
+                attach_iou_target=self.attach_iou_target)
         out = [self.loss_single(cls_scores[l], bbox_preds[l], iou_preds[l], labels[l], label_w[l],
                                 bbox_t[l], bbox_w[l], level_anchors[l], num_total_samples,
                                 gt_bboxes, cfg, level=l, geom=geom)

@@ -711,18 +711,10 @@ def anchor_targets(geom, gt_bboxes, gt_labels, pad_shapes, pos_iou_thr, neg_iou_
     if min(sizes) < 1:
         raise ValueError('No gt or bboxes')
     gmax = max(sizes)
-    boxes = torch.zeros((B, gmax, 4), dtype=torch.float32, device=dev)
-    labs = torch.zeros((B, gmax), dtype=torch.int64, device=dev) if gt_labels is not None else None
-    for i, g_ in enumerate(gt_bboxes):
-        boxes[i, :sizes[i]] = g_.to(torch.float32)
-        if labs is not None:
-            labs[i, :sizes[i]] = gt_labels[i].to(torch.int64)
-    num_gt = torch.tensor(sizes, dtype=torch.int32).to(dev, non_blocking=True)
     vhw = []
     for (h, w) in [tuple(p[:2]) for p in pad_shapes]:
         vhw.append([[min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw)]
                     for s, (fh, fw) in zip(geom.strides, geom.featmap_sizes)])
-    vhw = torch.tensor(vhw, dtype=torch.int32).to(dev, non_blocking=True)
     N = geom.N
     labels = torch.empty(B * N, dtype=torch.int64, device=dev)
     lw = torch.empty(B * N, dtype=torch.float32, device=dev)
@@ -730,10 +722,37 @@ def anchor_targets(geom, gt_bboxes, gt_labels, pad_shapes, pos_iou_thr, neg_iou_
     bw = torch.empty(B * N * 4, dtype=torch.float32, device=dev)
     counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
     scratch = torch.empty((B, gmax), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().ia_anchor_targets(
-        geom.ref(), _ptr(boxes), _ptr(labs), _ptr(num_gt), B, gmax, _ptr(vhw), float(pos_iou_thr),
-        float(neg_iou_thr), float(min_pos_iou), float(pos_weight), _ptr(scratch), _ptr(labels),
-        _ptr(lw), _ptr(bt), _ptr(bw), _ptr(counts), _stream()), 'ia_anchor_targets')
+    if B <= _lib.IA_MAX_TARGET_BATCH:
+        # gt tensors stay where the loader put them: their pointers and sizes ride in the kernel
+        # arguments (no padded staging copy, no host-to-device transfer)
+        keep = [g_.to(torch.float32).contiguous() for g_ in gt_bboxes]
+        gp = (C.c_void_p * B)(*[g_.data_ptr() for g_ in keep])
+        if gt_labels is not None:
+            keep_l = [l_.to(torch.int64).contiguous() for l_ in gt_labels]
+            lp = (C.c_void_p * B)(*[l_.data_ptr() for l_ in keep_l])
+        else:
+            lp = None
+        ng = (C.c_int32 * B)(*sizes)
+        vh = (C.c_int32 * (B * geom.L * 2))(*[v for img in vhw for lv in img for v in lv])
+        _lib.check(_lib.lib().ia_anchor_targets_ptrs(
+            geom.ref(), gp, lp, ng, B, vh, float(pos_iou_thr), float(neg_iou_thr),
+            float(min_pos_iou), float(pos_weight), _ptr(scratch), _ptr(labels), _ptr(lw), _ptr(bt),
+            _ptr(bw), _ptr(counts), _stream()), 'ia_anchor_targets_ptrs')
+    else:
+        boxes = torch.zeros((B, gmax, 4), dtype=torch.float32, device=dev)
+        labs = torch.zeros((B, gmax), dtype=torch.int64, device=dev) \
+            if gt_labels is not None else None
+        for i, g_ in enumerate(gt_bboxes):
+            boxes[i, :sizes[i]] = g_.to(torch.float32)
+            if labs is not None:
+                labs[i, :sizes[i]] = gt_labels[i].to(torch.int64)
+        num_gt = torch.tensor(sizes, dtype=torch.int32).to(dev, non_blocking=True)
+        vhw_t = torch.tensor(vhw, dtype=torch.int32).to(dev, non_blocking=True)
+        _lib.check(_lib.lib().ia_anchor_targets(
+            geom.ref(), _ptr(boxes), _ptr(labs), _ptr(num_gt), B, gmax, _ptr(vhw_t),
+            float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou), float(pos_weight),
+            _ptr(scratch), _ptr(labels), _ptr(lw), _ptr(bt), _ptr(bw), _ptr(counts), _stream()),
+            'ia_anchor_targets')
     out = ([], [], [], [])
     off = 0
     for n_l in geom.level_anchors:
@@ -744,6 +763,121 @@ def anchor_targets(geom, gt_bboxes, gt_labels, pad_shapes, pos_iou_thr, neg_iou_
         out[3].append(bw[4 * B * off:4 * B * (off + n_l)].view(B, n_l, 4))
         off += n_l
     return out[0], out[1], out[2], out[3], counts
+
+
+class LevelLosses(list):
+    """per-level (1,)-shaped loss tensors, like the reference's lists, plus `.total` = their sum
+    computed by the finalize kernel (differentiable): train.parse_losses adds three tensors
+    instead of reducing fifteen."""
+    total = None
+
+
+_ZERO1 = {}
+
+
+def _zero1(dev):
+    z = _ZERO1.get(dev)
+    if z is None:
+        z = _ZERO1[dev] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """the three losses of every level: 3 launches forward, 2 backward (csrc/headloss.hip).
+    Outputs: 3L per-level (1,) tensors and 3 totals, views of one result vector."""
+
+    @staticmethod
+    def forward(ctx, geom, targets, cfg, *outs):
+        L = geom.L
+        cls, reg, iou = outs[:L], outs[L:2 * L], outs[2 * L:3 * L]
+        for t in outs:
+            _require_gpu(t, 'head output')
+        cls, reg, iou = [[t.contiguous() for t in x] for x in (cls, reg, iou)]
+        B, dev, dt = cls[0].shape[0], cls[0].device, _dtype_code(cls[0])
+        if any(_dtype_code(t) != dt for t in cls + reg + iou):
+            raise TypeError('head outputs must share one dtype')
+        p = LevelPtrs()
+        for l in range(L):
+            p.cls[l], p.reg[l], p.iou[l] = cls[l].data_ptr(), reg[l].data_ptr(), iou[l].data_ptr()
+        labels, lw, bt, bw, counts, avg = targets
+        labels = [t.contiguous().to(torch.int64) for t in labels]
+        lw = [t.contiguous().to(torch.float32) for t in lw]
+        bt = [t.contiguous().to(torch.float32) for t in bt]
+        bw = [t.contiguous().to(torch.float32) for t in bw]
+        ht = _lib.HeadTargets()
+        for l in range(L):
+            ht.labels[l], ht.label_weights[l] = labels[l].data_ptr(), lw[l].data_ptr()
+            ht.bbox_targets[l], ht.bbox_weights[l] = bt[l].data_ptr(), bw[l].data_ptr()
+        avg_dev = None
+        if counts is not None:
+            ht.counts = counts.data_ptr()
+        elif torch.is_tensor(avg):
+            avg_dev = avg.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+            ht.avg_factor_dev = avg_dev.data_ptr()
+        else:
+            ht.avg_factor = float(avg)
+        hc = _lib.HeadLossCfg(*cfg)
+        res = torch.empty(3 * L + 4, dtype=torch.float32, device=dev)
+        g = geom.with_layout(_lib.IA_LAYOUT_NCHW)
+        nbytes = _lib.lib().ia_head_loss_workspace_bytes(g.ref(), B)
+        if nbytes == 0:
+            raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_head_loss')
+        # own buffer (not the shared inference workspace): it carries the packed targets from
+        # the forward to the backward call
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().ia_head_loss_fwd(g.ref(), C.byref(p), dt, B, C.byref(ht),
+                                               C.byref(hc), _ptr(ws), nbytes, _ptr(res),
+                                               _stream()), 'ia_head_loss_fwd')
+        ctx.ws = ws
+        ctx.geom, ctx.cfg, ctx.B, ctx.dt = g, hc, B, dt
+        ctx.keep = (cls, reg, iou, labels, lw, bt, bw, counts, avg_dev, p, ht)
+        ctx.res = res
+        ctx.set_materialize_grads(False)
+        return tuple(res[:3 * L + 3].view(3 * L + 3, 1).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cls, reg, iou, labels, lw, bt, bw, counts, avg_dev, p, ht = ctx.keep
+        L, dev = ctx.geom.L, cls[0].device
+        z = _zero1(dev)
+        gin = torch.cat([z if g is None else g.detach().reshape(1).to(torch.float32) for g in gs])
+        gp = LevelPtrs()
+        grads = [[torch.empty(t.shape, dtype=torch.float32, device=dev) for t in x]
+                 for x in (cls, reg, iou)]
+        for l in range(L):
+            gp.cls[l], gp.reg[l], gp.iou[l] = (grads[0][l].data_ptr(), grads[1][l].data_ptr(),
+                                               grads[2][l].data_ptr())
+        _lib.check(_lib.lib().ia_head_loss_bwd(ctx.geom.ref(), C.byref(p), ctx.dt, ctx.B,
+                                               C.byref(ht), C.byref(ctx.cfg), _ptr(ctx.ws),
+                                               _ptr(ctx.res), _ptr(gin), C.byref(gp), _stream()),
+                   'ia_head_loss_bwd')
+        out = [g if g.dtype == t.dtype else g.to(t.dtype)
+               for x, gx in zip((cls, reg, iou), grads) for t, g in zip(x, gx)]
+        return (None, None, None) + tuple(out)
+
+
+def head_loss(geom, cls, reg, iou, labels, label_weights, bbox_targets, bbox_weights, counts=None,
+              avg_factor=None, gamma=2.0, alpha=0.25, loss_weight_cls=1.0, beta=0.11,
+              loss_weight_bbox=1.0, attach_iou_target=True, exact_large_logits=False):
+    """FocalLoss(gamma=2) + SmoothL1Loss + IoU BCE of every pyramid level in one autograd node.
+    Normaliser: `counts` ((B,2) of anchor_targets: sum_b max(n_pos_b, 1), stays on the device), else
+    `avg_factor` (python number or device scalar).  -> dict of three LevelLosses lists."""
+    if counts is None and avg_factor is None:
+        raise ValueError('head_loss needs counts or avg_factor')
+    if float(gamma) != 2.0:
+        raise ValueError('the all-levels kernel is specialised for gamma = 2')
+    L = geom.L
+    cfg = (float(gamma), float(alpha), float(loss_weight_cls), float(beta), float(loss_weight_bbox),
+           int(bool(attach_iou_target)), int(bool(exact_large_logits)))
+    targets = (list(labels), list(label_weights), list(bbox_targets), list(bbox_weights), counts,
+               avg_factor)
+    flat = _HeadLossFn.apply(geom, targets, cfg, *(list(cls) + list(reg) + list(iou)))
+    out = {}
+    for k, name in enumerate(('loss_cls', 'loss_bbox', 'losses_iou')):
+        lst = LevelLosses(flat[k * L:(k + 1) * L])
+        lst.total = flat[3 * L + k]
+        out[name] = lst
+    return out
 
 
 class _SigmoidFocalLossOpFn(torch.autograd.Function):

@@ -23,7 +23,11 @@ def parse_losses(losses):
         if isinstance(value, torch.Tensor):
             log_vars[name] = value.mean()
         elif isinstance(value, list):
-            log_vars[name] = sum(v.mean() for v in value)
+            # the all-levels loss kernels deliver the sum over the levels with the list
+            # (ops.LevelLosses.total); other lists are reduced like the reference does
+            total = getattr(value, 'total', None)
+            log_vars[name] = total.reshape(()) if total is not None \
+                else sum(v.mean() for v in value)
         else:
             raise TypeError('{} is not a tensor or list of tensors'.format(name))
     loss = sum(v for k, v in log_vars.items() if 'loss' in k)

@@ -242,3 +242,166 @@ def test_head_loss_iou_balanced_vs_reference(ops, fx, golden_dir):
             want = fb[key].astype(np.float64)
             got = g.cpu().numpy().reshape(-1)[fb[key + '_idx']].astype(np.float64)
             assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), key
+
+
+# ------------------------------------------------------------------ all levels in one node
+def _head_and_inputs(fx, dtype=torch.float32):
+    from iouaware.head import IoUawareRetinaHead
+    from test_host_targets import HEAD_KW
+    f, cls, reg, iou, B, (ph, pw) = fx
+    ih, iw = int(f['img'][0]), int(f['img'][1])
+    head = IoUawareRetinaHead(**HEAD_KW).cuda()
+    metas = [synth.img_meta(ih, iw, ph, pw) for _ in range(B)]
+    gts = [torch.from_numpy(f['gt_bboxes_%d' % b]).cuda() for b in range(B)]
+    gls = [torch.from_numpy(f['gt_labels_%d' % b]).cuda() for b in range(B)]
+    mk = lambda xs: [t.requires_grad_(True) for t in G.to_dev(xs, dtype)]     # noqa: E731
+    return head, metas, gts, gls, mk(cls), mk(reg), mk(iou)
+
+
+@pytest.mark.parametrize('attach', [True, False])
+def test_all_levels_loss_node_equals_per_level_kernels(ops, fx, attach):
+    """csrc/headloss.hip (3 + 2 launches) against the per-level kernels of csrc/loss.hip on the
+    same targets: losses to 1e-6, gradients to 1e-6 of their scale (focal: other operation
+    order, hardware transcendentals on both sides)."""
+    from test_host_targets import TRAIN_CFG
+    outs = []
+    for fuse in (True, False):
+        head, metas, gts, gls, c, r, i = _head_and_inputs(fx)
+        head.fuse_levels, head.attach_iou_target = fuse, attach
+        losses = head.loss(c, r, i, gts, gls, metas, TRAIN_CFG)
+        assert isinstance(losses['loss_cls'], ops.LevelLosses) == fuse
+        # upstream gradients that differ per loss and level
+        w = torch.arange(1, 16, device='cuda', dtype=torch.float32).reshape(3, 5) * 0.25
+        total = sum(w[k, l] * losses[key][l] for k, key in
+                    enumerate(('loss_cls', 'loss_bbox', 'losses_iou')) for l in range(5))
+        total.sum().backward()
+        outs.append((losses, [t.grad for t in c], [t.grad for t in r], [t.grad for t in i]))
+    (la, ca, ra, ia_), (lb, cb, rb, ib) = outs
+    for k in la:
+        for x, y in zip(la[k], lb[k]):
+            assert x.shape == (1,) and rel(float(x), float(y)) < 1e-6, k
+        assert rel(float(la[k].total), sum(float(v) for v in lb[k])) < 1e-6
+    for name, xs, ys in (('cls', ca, cb), ('reg', ra, rb), ('iou', ia_, ib)):
+        for l, (x, y) in enumerate(zip(xs, ys)):
+            scale = float(y.abs().max())
+            assert float((x - y).abs().max()) <= 1e-6 * max(scale, 1e-30), (name, l)
+            assert x.shape == y.shape and x.dtype == y.dtype
+
+
+def test_all_levels_loss_node_total_path_and_reference(ops, fx):
+    """parse_losses adds the three `.total` tensors; gradients through them equal the reference's
+    autograd gradients (tests/golden/losses_small.npz, 1e-4 / 2e-4 like the per-level test)."""
+    from iouaware.train import parse_losses
+    from test_host_targets import TRAIN_CFG
+    f = fx[0]
+    head, metas, gts, gls, c, r, i = _head_and_inputs(fx)
+    losses = head.loss(c, r, i, gts, gls, metas, TRAIN_CFG)
+    loss, log_vars = parse_losses(losses)
+    want = float(f['loss_cls'].sum() + f['loss_bbox'].sum() + f['losses_iou'].sum())
+    assert rel(float(loss), want) < 1e-4
+    for k in ('loss_cls', 'loss_bbox', 'losses_iou'):
+        assert rel(float(log_vars[k]), float(f[k].sum())) < 1e-4
+    loss.backward()
+    for l in range(5):
+        for key, g in (('g_cls_%d' % l, c[l].grad), ('g_reg_%d' % l, r[l].grad),
+                       ('g_iou_%d' % l, i[l].grad)):
+            idx = f[key + '_idx']
+            want = f[key + '_attached'].astype(np.float64)
+            got = g.cpu().numpy().reshape(-1)[idx].astype(np.float64)
+            assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), key
+
+
+def test_all_levels_loss_node_torch_targets_and_bf16(ops, fx):
+    """host-number normaliser (torch target path) and bf16 head outputs"""
+    from iouaware.targets import anchor_target
+    from test_host_targets import TRAIN_CFG
+    f = fx[0]
+    head, metas, gts, gls, c, r, i = _head_and_inputs(fx)
+    sizes = [tuple(t.shape[-2:]) for t in c]
+    anchors, flags = head.get_anchors(sizes, metas, device='cuda')
+    t = anchor_target(anchors, flags, gts, metas, head.target_means, head.target_stds, TRAIN_CFG,
+                      gt_labels_list=gls, label_channels=80, sampling=False)
+    geom = head.geometry(sizes, -1)
+    out = ops.head_loss(geom, c, r, i, t[0], t[1], t[2], t[3], avg_factor=t[4])
+    for k in ('loss_cls', 'loss_bbox', 'losses_iou'):
+        got = np.array([float(x) for x in out[k]])
+        assert np.all(np.abs(got - f[k]) <= 1e-4 * np.maximum(np.abs(f[k]), 1e-6)), k
+    out2 = ops.head_loss(geom, c, r, i, t[0], t[1], t[2], t[3],
+                         avg_factor=torch.tensor([float(t[4])], device='cuda'))
+    assert all(float(a) == float(b) for k in out for a, b in zip(out[k], out2[k]))
+    # bf16 logits: the kernels read bf16, accumulate in fp32 / fp64, return bf16 gradients
+    hb, _, _, _, cb, rb, ib = _head_and_inputs(fx, torch.bfloat16)
+    cf = [x.detach().float().requires_grad_(True) for x in cb]
+    rf = [x.detach().float().requires_grad_(True) for x in rb]
+    if_ = [x.detach().float().requires_grad_(True) for x in ib]
+    a = ops.head_loss(geom, cb, rb, ib, t[0], t[1], t[2], t[3], avg_factor=t[4])
+    b = ops.head_loss(geom, cf, rf, if_, t[0], t[1], t[2], t[3], avg_factor=t[4])
+    sum(v.total for v in a.values()).sum().backward()
+    sum(v.total for v in b.values()).sum().backward()
+    for k in a:
+        for x, y in zip(a[k], b[k]):
+            assert rel(float(x), float(y)) < 1e-6          # same (bf16-exact) inputs
+    for xs, ys in ((cb, cf), (rb, rf), (ib, if_)):
+        for x, y in zip(xs, ys):
+            assert x.grad.dtype == torch.bfloat16
+            assert torch.equal(x.grad, y.grad.to(torch.bfloat16))
+
+
+def test_all_levels_focal_full_size_vs_oracle(ops, oracle_lib):
+    """800x1344, batch 2: the all-levels focal kernel against the fp64-summing oracle per level
+    (1e-5 on the sums, 1e-5 of the gradient scale), incl. ignored anchors and every class id"""
+    ph, pw, B = 800, 1344, 2
+    geom, base = G.geometry(ph, pw, -1)
+    cls, reg, iou = synth.head_outputs(31, B, ph, pw, 'A')
+    rs = np.random.RandomState(5)
+    labels, lw, bt, bw = [], [], [], []
+    for (h, w) in geom.featmap_sizes:
+        n = h * w * synth.A
+        lab = np.zeros((B, n), np.int64)
+        pos = rs.rand(B, n) < 0.004
+        lab[pos] = rs.randint(1, 81, int(pos.sum()))
+        wgt = (rs.rand(B, n) > 0.05).astype(np.float32)          # 5 % ignored
+        labels.append(lab); lw.append(wgt)
+        bt.append((rs.standard_normal((B, n, 4)) * 0.2 * pos[..., None]).astype(np.float32))
+        bw.append(np.repeat(pos[..., None].astype(np.float32), 4, -1))
+    dev = lambda xs: [torch.from_numpy(x).cuda() for x in xs]    # noqa: E731
+    c = [t.requires_grad_(True) for t in G.to_dev(cls)]
+    r = [t.requires_grad_(True) for t in G.to_dev(reg)]
+    i = [t.requires_grad_(True) for t in G.to_dev(iou)]
+    avg = 37.0
+    out = ops.head_loss(geom, c, r, i, dev(labels), dev(lw), dev(bt), dev(bw), avg_factor=avg)
+    sum(v.total for v in out.values()).sum().backward()
+    for l in range(geom.L):
+        so, go = oracle_lib.focal_loss(cls[l], labels[l], lw[l], synth.A, 2.0, 0.25,
+                                       gscale=1.0 / avg)
+        assert rel(float(out['loss_cls'][l]), so / avg) < 1e-5, l
+        g = c[l].grad.cpu().numpy()
+        assert np.abs(g - go).max() <= 1e-5 * np.abs(go).max(), l
+        s1, g1 = oracle_lib.smooth_l1(reg[l], bt[l], bw[l], synth.A, 0.11, gscale=1.0 / avg)
+        s2, tgt, g_iou, g_box = oracle_lib.iou_bce(reg[l], iou[l], bt[l], bw[l], base[l],
+                                                   synth.STRIDES[l], gscale=1.0 / avg)
+        assert rel(float(out['loss_bbox'][l]), s1 / avg) < 1e-5, l
+        assert rel(float(out['losses_iou'][l]), s2 / avg) < 1e-5, l
+        gr = r[l].grad.cpu().numpy()
+        assert np.abs(gr - (g1 + g_box)).max() <= 1e-6 * max(np.abs(g1 + g_box).max(), 1e-30), l
+        gi = i[l].grad.cpu().numpy()
+        assert np.abs(gi - g_iou).max() <= 1e-6 * max(np.abs(g_iou).max(), 1e-30), l
+
+
+def test_anchor_targets_padded_entry_point_for_large_batches(ops):
+    """batches beyond IA_MAX_TARGET_BATCH take ia_anchor_targets (padded gt tensor): same targets"""
+    from iouaware import _lib
+    B = _lib.IA_MAX_TARGET_BATCH + 1
+    ph, pw = 128, 160
+    geom, _ = G.geometry(ph, pw, -1)
+    gts, gls = synth.train_targets(3, B, ph, pw, max_gt=6)
+    gtb = [torch.from_numpy(x).cuda() for x in gts]
+    gtl = [torch.from_numpy(x).cuda() for x in gls]
+    big = ops.anchor_targets(geom, gtb, gtl, [(ph, pw, 3)] * B, 0.5, 0.4, 0.0, -1)
+    for b0 in (0, 9):
+        sl = slice(b0, b0 + 8)
+        small = ops.anchor_targets(geom, gtb[sl], gtl[sl], [(ph, pw, 3)] * 8, 0.5, 0.4, 0.0, -1)
+        assert torch.equal(big[4][sl], small[4])
+        for k in range(4):
+            for l in range(geom.L):
+                assert torch.equal(big[k][l][sl], small[k][l])

@@ -1,0 +1,68 @@
+"""Loss part of one training iteration (BASELINE config 5 shapes: B images of 800x1344, fixed head
+outputs): device target assignment + the three losses of all levels forward + parse_losses +
+backward.  Prints wall per iteration (HIP events); under rocprofv3 the kernel trace is reduced by
+tools/summarize_trace.py with the marker `k_box_ml<float, true>` (last kernel of an iteration).
+
+    python tools/time_headloss.py [B] [per_level]
+"""
+import os
+import sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import synth  # noqa: E402
+from iouaware.config import ConfigDict  # noqa: E402
+from iouaware.head import IoUawareRetinaHead  # noqa: E402
+from iouaware.train import parse_losses  # noqa: E402
+import bench  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+per_level = len(sys.argv) > 2 and sys.argv[2] == 'per_level'
+TRAIN_CFG = ConfigDict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4,
+                                     min_pos_iou=0, ignore_iof_thr=-1), allowed_border=-1,
+                       pos_weight=-1, debug=False)
+kw = dict(bench.MODEL['bbox_head'])
+kw.pop('type')
+head = IoUawareRetinaHead(**kw).cuda()
+head.fuse_levels = not per_level
+cls, reg, iou = synth.head_outputs(3, B, 800, 1344, 'A')
+outs = [[torch.from_numpy(t).cuda().requires_grad_(True) for t in x] for x in (cls, reg, iou)]
+gts, gls = synth.train_targets(5, B, 800, 1333, max_gt=20)
+gtb = [torch.from_numpy(x).cuda() for x in gts]
+gtl = [torch.from_numpy(x).cuda() for x in gls]
+metas = [synth.img_meta(800, 1333, 800, 1344) for _ in range(B)]
+
+
+FWD_ONLY = os.environ.get('FWD_ONLY')
+
+
+def it():
+    if FWD_ONLY:
+        with torch.no_grad():
+            head.loss(*outs, gtb, gtl, metas, TRAIN_CFG)
+        return
+    for x in outs:
+        for t in x:
+            t.grad = None
+    losses = head.loss(*outs, gtb, gtl, metas, TRAIN_CFG)
+    loss, _ = parse_losses(losses)
+    loss.backward()
+
+
+for _ in range(5):
+    it()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+n = 20
+e0.record()
+for _ in range(n):
+    it()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+print('B=%d %s: targets + losses fwd + bwd  %.3f ms per iteration' %
+      (B, 'per-level kernels' if per_level else 'all-levels kernels', ms))
+print('focal algorithmic bytes: fwd %.1f MB, bwd %.1f MB per iteration' %
+      (66931200 * B / 1e6, 131443200 * B / 1e6))
