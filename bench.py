@@ -16,13 +16,22 @@ Weights are random-init (no checkpoints offline), data synthetic; images are
 sharded data-parallel (weak scaling: 8 images per GPU per step).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline     -- the row-max kernel over the head logits (SURVEY 8d's unit; k_rowmax_nhwc for
-                  this channels-last network, HBM bound): algorithmic bytes per launch / average
-                  launch duration, timed with HIP events on the launch stream inside the timed
-                  steps;
-  cpu_baseline -- the same workload on the host cores (rank 0, N=1 only): PyTorch-CPU
-                  convolutions + the C oracle (oracle/, a port of the reference CPU path) on a
-                  bounded sample.
+  roofline     -- the row-max kernel over the head logits (k_rowmax_nhwc for this channels-last
+                  network, HBM bound).  `achieved` = the bytes THAT kernel moves per launch (class
+                  + IoU logits read once, row maxima written: 66 124 800 B per image; the box
+                  deltas are not touched by it) / its average launch duration, HIP events on the
+                  launch stream inside the timed steps.  Sub-entries:
+                    stage  SURVEY 8(d)'s decode-stage unit: 68 544 000 B per image (cls + reg + iou)
+                           / the time of row-max + select + gather (events around all launches);
+                    wino   the Winograd transforms (largest hand-written time of the step): their
+                           algorithmic bytes / their summed durations, events in 2 extra steps
+                           after the timed region (43 launches per step);
+  cpu_baseline -- the same workload on the host cores (rank 0, N=1 only), one image: PyTorch-CPU
+                  convolutions on all cores + the C oracle (oracle/, a port of the reference CPU
+                  path, 1 thread); `single_thread` repeats it with one torch thread;
+  train        -- BASELINE config 5 on this GPU (rank 0, N=1 only): R-50 training iterations at
+                  batch 4 (forward, HIP target assignment + loss kernels, backward, grad clip,
+                  SGD), img/s, measured after the inference timing.
 """
 import argparse
 import json
@@ -45,6 +54,9 @@ from iouaware.config import ConfigDict  # noqa: E402
 IMG_H, IMG_W, PAD_H, PAD_W = 800, 1333, 800, 1344
 BATCH = 8
 HEAD_BYTES_PER_IMAGE = 68544000          # cls+reg+iou logits, fp32, read once
+# what k_rowmax[_nhwc] itself moves: cls (64 512 000) + iou (806 400) read, row maxima (806 400)
+# written; the 3 225 600 B of box deltas are read by k_gather for the 4 693 candidates only
+ROWMAX_BYTES_PER_IMAGE = 64512000 + 806400 + 806400
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 MODEL = dict(
@@ -94,7 +106,7 @@ class Stepper(object):
         self.model, self.imgs, self.world = model, imgs, world
         self.metas = metas(imgs.shape[0])
         self.cfg = model.test_cfg
-        self.rowmax_ms = []
+        self.rowmax_ms, self.stage_ms = [], []
         self.pending = []
         self.last = None
         self.nhwc = False
@@ -113,14 +125,15 @@ class Stepper(object):
             # consumed in place (k_rowmax_nhwc); NCHW ones by k_rowmax.
             geom = ops.geometry_for(geom, cls, reg, iou)
             self.nhwc = bool(geom.layout)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1, e2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e0.record()
             rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
             e1.record()
-            self.pending.append((e0, e1))
             idx = ops.select_topk(geom, rm)
             boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors,
                                                       True)
+            e2.record()
+            self.pending.append((e0, e1, e2))
             dets, labels, rows, num = ops.multiclass_nms_lazy(boxes, scores_t, geom.R,
                                                               self.cfg.score_thr,
                                                               self.cfg.nms.iou_thr,
@@ -136,15 +149,28 @@ class Stepper(object):
 
     def collect(self):
         torch.cuda.synchronize()
-        for e0, e1 in self.pending:
+        for e0, e1, e2 in self.pending:
             self.rowmax_ms.append(e0.elapsed_time(e1))
+            self.stage_ms.append(e0.elapsed_time(e2))
         self.pending = []
 
 
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(model, stepper):
-    """Same workload on the host cores, bounded sample: ONE image of the batch.
-    convs: PyTorch CPU (all threads); post-conv path: the C oracle (1 thread), which is a
-    port of the reference CPU path pinned against it by tests/golden."""
+    """Same workload on the host cores, bounded sample: ONE image of the batch, twice:
+    convs on all torch threads, then on one thread; the post-conv path is the C oracle (1 thread:
+    the reference's NMS is serial by construction), a port of the reference CPU path pinned
+    against it by tests/golden."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import copy
     import oracle
@@ -166,20 +192,137 @@ def cpu_baseline(model, stepper):
                                    TEST_CFG['score_thr'], TEST_CFG['nms']['iou_thr'],
                                    TEST_CFG['max_per_img'])
     t_post = time.time() - t0
+    torch.set_num_threads(1)
+    try:
+        with torch.no_grad():
+            t0 = time.time()
+            cpu_model.forward_head(img)
+            t_conv1 = time.time() - t0
+    finally:
+        torch.set_num_threads(threads)
     total = t_conv + t_post
+    into_nms = int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum())
+    name = cpu_model_name()
     return dict(value=round(1.0 / total, 4), unit='img/s', cores=threads, kind='port',
+                cpu=name, host_cores=os.cpu_count(),
                 sample='1 image of the batch (3x800x1344): PyTorch-CPU convs %.2f s on %d threads'
-                       ' + C oracle get_bboxes %.2f s on 1 thread (%d boxes into NMS); host has'
-                       ' %d cores' % (t_conv, threads, t_post,
-                                      int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum()),
-                                      os.cpu_count()))
+                       ' + C oracle get_bboxes %.2f s on 1 thread (%d boxes into NMS); host: %s,'
+                       ' %d cores' % (t_conv, threads, t_post, into_nms, name, os.cpu_count()),
+                single_thread=dict(value=round(1.0 / (t_conv1 + t_post), 4), unit='img/s', cores=1,
+                                   sample='the same image: PyTorch-CPU convs %.2f s on 1 thread + '
+                                          'C oracle %.2f s' % (t_conv1, t_post)))
+
+
+TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4,
+                               min_pos_iou=0, ignore_iof_thr=-1),
+                 allowed_border=-1, pos_weight=-1, debug=False)
+TRAIN_BATCH = 4                           # imgs_per_gpu of the reference's 4-GPU config (:78)
+
+
+def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels_last=False):
+    """BASELINE config 5, one GPU: whole training iterations of R-50 IoU-aware RetinaNet at
+    800x1344, batch 4, fp32 -- forward, device target assignment + all-levels loss kernels,
+    backward, gradient clipping, SGD (reference mmdet/apis/train.py:38-45, optimizer_config of
+    the configs).  Gradient all-reduce is not part of a single-GPU measurement."""
+    from iouaware.train import build_optimizer, train_step
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import synth
+    # MIOpen immediate mode: find mode times every candidate of every forward / backward-data /
+    # backward-weight convolution in a fresh process (~8 minutes here) for ~7 % more img/s
+    torch.backends.cudnn.benchmark = bool(find)
+    torch.manual_seed(0)
+    model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=ConfigDict(TRAIN_CFG),
+                                    test_cfg=ConfigDict(TEST_CFG)).to(device).train()
+    opt = build_optimizer(model, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001))
+    g = torch.Generator(device=device).manual_seed(7)
+    img = torch.randn(TRAIN_BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        img = img.contiguous(memory_format=torch.channels_last)
+    gts, gls = synth.train_targets(5, TRAIN_BATCH, IMG_H, IMG_W, max_gt=20)
+    gtb = [torch.from_numpy(x).to(device) for x in gts]
+    gtl = [torch.from_numpy(x).to(device) for x in gls]
+    ms = metas(TRAIN_BATCH)
+    clip = dict(max_norm=35, norm_type=2)
+    for _ in range(warmup):
+        lv = train_step(model, opt, img, ms, gtb, gtl, grad_clip=clip)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        lv = train_step(model, opt, img, ms, gtb, gtl, grad_clip=clip)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    # loss part alone on the last head outputs: HIP events around targets + losses fwd + bwd
+    with torch.no_grad():
+        outs = model.bbox_head(model.extract_feat(img))
+    outs = [[t.detach().requires_grad_(True) for t in o] for o in outs]
+    from iouaware.train import parse_losses
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def run_loss_part():
+        for o in outs:
+            for t in o:
+                t.grad = None
+        loss, _ = parse_losses(model.bbox_head.loss(*outs, gtb, gtl, ms, model.train_cfg))
+        loss.backward()
+    for _ in range(3 if loss_part else 0):
+        run_loss_part()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10 if loss_part else 0):
+        run_loss_part()
+    e1.record()
+    torch.cuda.synchronize()
+    return dict(value=round(TRAIN_BATCH / dt, 2), unit='img/s', ms_per_iter=round(dt * 1e3, 2),
+                batch=TRAIN_BATCH, dtype='fp32', iters=iters, warmup=warmup,
+                loss_part_ms=round(e0.elapsed_time(e1) / 10, 3) if loss_part else None,
+                miopen_find_mode=bool(find),
+                loss=round(float(lv['loss']), 4),
+                workload='R-50 IoU-aware RetinaNet training iteration, 3x800x1344, batch 4 on one '
+                         'GPU: fwd + HIP targets / losses + bwd + clip + SGD (random init, synthetic)')
+
+
+PMC_PROFILE = 'r02_head_pmc.json'
+
+
+def wino_roofline(stepper, steps=2):
+    """events around every Winograd transform launch of `steps` extra (untimed) steps"""
+    from iouaware import winograd
+    winograd.TIMING = []
+    try:
+        for _ in range(steps):
+            stepper.step(timed=False)
+        torch.cuda.synchronize()
+        rec = [(k, e0.elapsed_time(e1), b) for k, e0, e1, b in winograd.TIMING]
+    finally:
+        winograd.TIMING = None
+    if not rec:
+        return None
+    ms = sum(r[1] for r in rec)
+    nbytes = sum(r[2] for r in rec)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    per = {}
+    for kind in ('in', 'out'):
+        sel = [r for r in rec if r[0] == kind]
+        if sel:
+            per[kind] = dict(launches_per_step=len(sel) // steps,
+                             ms_per_step=round(sum(r[1] for r in sel) / steps, 3),
+                             achieved=round(sum(r[2] for r in sel) / (sum(r[1] for r in sel) * 1e-3)
+                                            / 1e9, 1))
+    return dict(bound='hbm', kernel='k_wino_in + k_wino_out', achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                launches_per_step=len(rec) // steps, ms_per_step=round(ms / steps, 3),
+                bytes_per_step=nbytes // steps, by_kernel=per,
+                note='algorithmic bytes: input transform 16 + 36, output transform 36 + 16 fp32 '
+                     'values per tile and channel; HIP events in %d steps after the timed region'
+                     % steps)
 
 
 def rowmax_traffic(kernel):
     """HBM bytes per k_rowmax launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 correction 2 x FETCH_SIZE; tools/collect_pmc.sh).  It is a
     batch-8 launch like the benchmark's; None when the profile is missing."""
-    path = os.path.join(ROOT, 'profiles', 'r01_head_pmc.json')
+    path = os.path.join(ROOT, 'profiles', PMC_PROFILE)
     try:
         with open(path) as f:
             prof = json.load(f)
@@ -196,6 +339,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train', action='store_true', help='skip the training sub-record')
+    ap.add_argument('--train-find', action='store_true',
+                    help='MIOpen find mode for the training sub-record (adds ~8 minutes)')
     ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
     ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
     ap.add_argument('--no-winograd', action='store_true',
@@ -244,12 +390,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    wino = wino_roofline(stepper) if rank == 0 else None
     if rank == 0:
         n_img = BATCH * world * args.steps
         ms_rowmax = float(np.mean(stepper.rowmax_ms))
+        ms_stage = float(np.mean(stepper.stage_ms))
         # the row-max kernel that ran: channels-last head outputs -> k_rowmax_nhwc<float, 20>
         rm_kernel = 'ia::k_rowmax_nhwc<float, 20>' if stepper.nhwc else 'ia::k_rowmax<float>'
-        achieved = HEAD_BYTES_PER_IMAGE * BATCH / (ms_rowmax * 1e-3) / 1e9
+        achieved = ROWMAX_BYTES_PER_IMAGE * BATCH / (ms_rowmax * 1e-3) / 1e9
+        stage = HEAD_BYTES_PER_IMAGE * BATCH / (ms_stage * 1e-3) / 1e9
         out = {
             'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN',
             'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': world,
@@ -264,14 +413,31 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': rm_kernel.split('::')[1].split('<')[0],
                          'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': rowmax_traffic(rm_kernel),
-                         'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
-                         'avg_launch_ms': round(ms_rowmax, 4)},
+                         'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': rowmax_traffic(rm_kernel),
+                         'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                           'separate passes, same batch-8 launch)' % PMC_PROFILE,
+                         'bytes_per_launch': ROWMAX_BYTES_PER_IMAGE * BATCH,
+                         'avg_launch_ms': round(ms_rowmax, 4),
+                         'stage': {'kernels': 'row-max + select + gather (SURVEY 8d decode stage)',
+                                   'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
+                                   'avg_ms': round(ms_stage, 4), 'achieved': round(stage, 1),
+                                   'frac': round(stage / HBM_PEAK_GBS, 4)},
+                         'wino': wino},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, stepper)
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not args.no_train:
+            del stepper, model, imgs
+            torch.cuda.empty_cache()
+            try:
+                out['train'] = train_record(device, find=args.train_find)
+            except Exception as exc:                     # the headline number must still print
+                out['train'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        else:
+            out['train'] = None
         print(json.dumps(out))
     if world > 1:
         dist.barrier(device_ids=[local_rank])

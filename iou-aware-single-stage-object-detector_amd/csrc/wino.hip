@@ -71,6 +71,10 @@ __device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t)
     const int q = t - w.tile_off[l];
     r.l = l; r.b = q / w.tpi[l];
     const int i = q - r.b * w.tpi[l];
+    // row-major tiles.  (Strips of 8 tile rows, column-major inside -- meant to shorten the L2
+    // reuse distance of the overlapping 6x6 patches -- measured SLOWER: 260 vs 245 us for the
+    // head's input transform, 222 vs 209 us for the output transform: neighbouring wavefronts
+    // then touch DRAM pages a whole pixel row apart.)
     const int ty = i / w.tx[l];
     r.y0 = 4 * ty; r.x0 = 4 * (i - ty * w.tx[l]);
     return r;
@@ -122,14 +126,42 @@ struct WinoInArgs {
     // BatchNorm + ReLU of the 1x1 convolution in front, applied on load instead of in a pass
     // of its own; padding stays zero
     const float *pre_scale, *pre_shift;
-    int32_t Ctot, Cg, T, pre_relu;
+    int32_t Ctot, Cg, T, pre_relu, tpw;
 };
+
+// lane -> (tile, channel quad).  Layers with fewer than 256 channels put several tiles into one
+// wavefront (64 channels: 4 tiles x 16 quads, 48 channels: 5 x 12) instead of leaving lanes idle:
+// the 64- and 128-channel bottleneck layers ran at 2.5-3.8 TB/s with 16 / 32 live lanes, the
+// 48-column reg|iou output transform at 0.7 TB/s with 12.
+struct LaneMap { int t, c; bool on; };
+__device__ __forceinline__ LaneMap lane_map(int Ctot, int T, int tpw)
+{
+    LaneMap m;
+    const int lane = threadIdx.x;
+    if (tpw > 1) {
+        const int q = Ctot >> 2;                       // quads per tile, <= 32 here
+        const int sub = lane / q;
+        const int tw = xcd_tile(blockIdx.x, (T + tpw - 1) / tpw) * tpw + sub;
+        m.t = tw; m.c = (lane - sub * q) * 4;
+        m.on = (sub < tpw) && (tw < T);
+    } else {
+        m.t = xcd_tile(blockIdx.x, T);
+        m.c = (blockIdx.y * 64 + lane) * 4;
+        m.on = (m.c < Ctot) && (m.t < T);
+    }
+    return m;
+}
+static int tiles_per_wave(int channels)
+{
+    const int q = channels / 4;
+    return (q < 64) ? (64 / q) : 1;
+}
 
 __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
 {
-    const int t = xcd_tile(blockIdx.x, a.T);
-    const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
-    if (c >= a.Ctot || t >= a.T) return;
+    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    if (!lm.on) return;
+    const int t = lm.t, c = lm.c;
     const TileRef r = locate_tile(a.lv, t);
     const int H = a.lv.H[r.l], W = a.lv.W[r.l];
     const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
@@ -195,14 +227,14 @@ struct WinoOutArgs {
     const float *M;                       // (groups * 36, T, Cg)
     const float *bias;                    // (groups * Cg) or NULL
     WinoSeg seg[kMaxSeg];
-    int32_t nseg, Ctot, Cg, T, relu;
+    int32_t nseg, Ctot, Cg, T, relu, tpw;
 };
 
 __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
 {
-    const int t = xcd_tile(blockIdx.x, a.T);
-    const int c = (blockIdx.y * 64 + threadIdx.x) * 4;
-    if (c >= a.Ctot || t >= a.T) return;
+    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    if (!lm.on) return;
+    const int t = lm.t, c = lm.c;
     const TileRef r = locate_tile(a.lv, t);
     const int H = a.lv.H[r.l], W = a.lv.W[r.l];
     const int g = c / a.Cg, cc = c - g * a.Cg;
@@ -226,6 +258,22 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
     const WinoSeg &sg = a.seg[si];
     const bool whole = (c >= sg.c0) && (c + 4 <= sg.c0 + sg.n) && (((sg.coff + c - sg.c0) & 3) == 0) &&
                        ((sg.Cdst & 3) == 0);
+    // a lane that straddles segments / padding, or whose destination is not 16-byte aligned
+    // (the 9-channel IoU output): destination of each of its four channels, resolved once
+    float *qdst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int qC[4] = {0, 0, 0, 0}, qoff[4] = {0, 0, 0, 0};
+    if (!whole) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = c + q;
+            for (int k = 0; k < a.nseg; ++k) {
+                const WinoSeg &z = a.seg[k];
+                if (ch >= z.c0 && ch < z.c0 + z.n) {
+                    qdst[q] = z.dst[r.l]; qC[q] = z.Cdst; qoff[q] = z.coff + (ch - z.c0);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                       // rows: Y = s A
         float4 o[4];
@@ -241,17 +289,11 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
             const size_t pix = ((size_t)r.b * H + y) * W + xx;
             if (whole) {
                 *reinterpret_cast<float4 *>(sg.dst[r.l] + pix * sg.Cdst + sg.coff + (c - sg.c0)) = v;
-            } else {                                    // a lane that straddles segments / padding
+            } else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ch = c + q;
-                    for (int k = 0; k < a.nseg; ++k) {
-                        const WinoSeg &z = a.seg[k];
-                        if (ch >= z.c0 && ch < z.c0 + z.n)
-                            z.dst[r.l][pix * z.Cdst + z.coff + (ch - z.c0)] = e[q];
-                    }
-                }
+                for (int q = 0; q < 4; ++q)
+                    if (qdst[q]) qdst[q][pix * qC[q] + qoff[q]] = e[q];
             }
         }
     }
@@ -287,7 +329,9 @@ int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int ch
     a.V = V;
     if (pre_scale && !pre_shift) return IA_E_ARG;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu ? 1 : 0;
-    dim3 grid((unsigned)((a.T + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
+    a.tpw = ia::tiles_per_wave(channels);
+    const int waves = (a.T + a.tpw - 1) / a.tpw;
+    dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
@@ -318,7 +362,9 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
             a.seg[k].dst[l] = s.dst[l];
         }
     }
-    dim3 grid((unsigned)((a.T + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
+    a.tpw = ia::tiles_per_wave(channels);
+    const int waves = (a.T + a.tpw - 1) / a.tpw;
+    dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_out, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }

@@ -91,14 +91,32 @@ class _Plan(object):
         return a
 
 
+# Measurement hook (bench.py): when TIMING is a list, every transform launch appends
+# (kind, start event, end event, algorithmic bytes) -- HIP events on the launch stream.  Bytes:
+# input transform = the activation read once (16 pixels per tile) + V written (36 per tile);
+# output transform = M read (36 per tile) + the activation written (16 per tile), fp32.
+TIMING = None
+
+
+def _timed(kind, nbytes, launch):
+    if TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TIMING.append((kind, e0, e1, nbytes))
+
+
 def input_transform(plan, xs, groups, out, pre=None):
     """pre = (scale or None, shift, relu): the input is read as relu?(x * scale + shift)"""
     ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
     ps, pb, pr = pre if pre is not None else (None, None, False)
-    _lib.check(_lib.lib().ia_wino_input_transform(C.byref(plan.geom), ptrs, int(xs[0].shape[1]),
-                                                  int(groups), _ptr(ps), _ptr(pb), int(bool(pr)),
-                                                  _ptr(out), _stream()),
-               'ia_wino_input_transform')
+    ch = int(xs[0].shape[1])
+    _timed('in', plan.T * ch * 4 * (16 + 36), lambda: _lib.check(
+        _lib.lib().ia_wino_input_transform(C.byref(plan.geom), ptrs, ch, int(groups), _ptr(ps),
+                                           _ptr(pb), int(bool(pr)), _ptr(out), _stream()),
+        'ia_wino_input_transform'))
     return out
 
 
@@ -110,10 +128,10 @@ def output_transform(plan, m, channels, groups, bias, relu, segments):
         segs[k].dst_channels, segs[k].dst_offset = int(dst[0].shape[1]), int(off)
         for l, t in enumerate(dst):
             segs[k].dst[l] = t.data_ptr()
-    _lib.check(_lib.lib().ia_wino_output_transform(C.byref(plan.geom), _ptr(m), int(channels),
-                                                   int(groups), _ptr(bias), int(bool(relu)),
-                                                   len(segments), segs, _stream()),
-               'ia_wino_output_transform')
+    _timed('out', plan.T * int(channels) * 4 * (36 + 16), lambda: _lib.check(
+        _lib.lib().ia_wino_output_transform(C.byref(plan.geom), _ptr(m), int(channels), int(groups),
+                                            _ptr(bias), int(bool(relu)), len(segments), segs,
+                                            _stream()), 'ia_wino_output_transform'))
 
 
 _LT_WS_BYTES = 128 << 20

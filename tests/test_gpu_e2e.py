@@ -214,7 +214,7 @@ def test_reference_call_signature_variants(golden_dir):
         assert a.shape == b.shape and G.close(a, b, TOL)
     sf = float(f['scale_factor'])
     cat0, cat2 = np.concatenate(r0), np.concatenate(r2)
-    assert cat0.shape == cat2.shape and np.allclose(cat0[:, :4] * sf, cat2[:, :4], rtol=1e-6, atol=1e-4)
+    assert cat0.shape == cat2.shape and G.close(cat0[:, :4] * sf, cat2[:, :4], TOL)
     # batch of two through the same entry point: a list of per-image results
     with torch.no_grad():
         two = m(return_loss=False, rescale=True, img=[torch.cat([x, x])], img_meta=[[meta, meta]])
