@@ -113,6 +113,14 @@ class Stepper(object):
 
     @torch.no_grad()
     def step(self, timed=False):
+        """one benchmark step = this rank's detections (+ the all-gather when N > 1)"""
+        dets, labels, num, cls, reg, iou = self.local_detections(timed)
+        if self.world > 1:
+            dets, labels, num = idist.all_gather_detections(dets, labels, num)
+        self.last = (dets, labels, num, cls, reg, iou)
+        return dets
+
+    def local_detections(self, timed=False):
         m = self.model
         cls, reg, iou = m.forward_head(self.imgs)
         head = m.bbox_head
@@ -142,10 +150,7 @@ class Stepper(object):
             dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
                                                      self.cfg.score_thr, self.cfg.nms.iou_thr,
                                                      self.cfg.max_per_img)
-        if self.world > 1:
-            dets, labels, num = idist.all_gather_detections(dets, labels, num)
-        self.last = (dets, labels, num, cls, reg, iou)
-        return dets
+        return dets, labels, num, cls, reg, iou
 
     def collect(self):
         torch.cuda.synchronize()
@@ -318,6 +323,27 @@ def wino_roofline(stepper, steps=2):
                      % steps)
 
 
+def timed_region(step, steps, warmup, world, sync, barrier, device):
+    """the driver's timing contract: W untimed warm-up steps, then EXACTLY K steps between
+    barrier + device synchronisation on both sides; the MAX over ranks of the elapsed time."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if world > 1:
+        barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def rowmax_traffic(kernel):
     """HBM bytes per k_rowmax launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 correction 2 x FETCH_SIZE; tools/collect_pmc.sh).  It is a
@@ -368,27 +394,19 @@ def main():
         imgs = imgs.contiguous(memory_format=torch.channels_last)
     stepper = Stepper(model, imgs, world)
 
-    for _ in range(args.warmup):
+    def step():
         stepper.step(timed=True)
-    stepper.collect()
-    stepper.rowmax_ms = []
 
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stepper.step(timed=True)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def warm():
+        # warm-up outside the timed region, and its event records dropped
+        for _ in range(args.warmup):
+            step()
+        stepper.collect()
+        stepper.rowmax_ms, stepper.stage_ms = [], []
+    warm()
+    elapsed = timed_region(step, args.steps, 0, world, torch.cuda.synchronize,
+                           lambda: dist.barrier(device_ids=[local_rank]), device)
     stepper.collect()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
 
     wino = wino_roofline(stepper) if rank == 0 else None
     if rank == 0:

@@ -120,3 +120,56 @@ def test_allreduce_grads_world2():
     ret = mp.get_context('spawn').Manager().dict()
     mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+
+
+# ------------------------------------------------------------------ bench.py's own N > 1 path
+def _bench_worker(rank, world, port, ret):
+    """drives bench.py's Stepper / timed_region (barriers, MAX over ranks of the elapsed time,
+    the per-step all-gather and its rank interleave) with the gloo backend on fake per-rank
+    detections -- the code the driver runs on 2/4/8 GPUs, executed before it ever does"""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import time
+    import bench
+    from iouaware import dist as idist
+    idist.init_dist('pytorch', backend='gloo')
+    B = 3
+
+    class FakeStepper(bench.Stepper):
+        def __init__(self):
+            self.world, self.calls, self.last = world, 0, None
+
+        def local_detections(self, timed=False):
+            # image j of this rank is dataset index j * world + rank (DistributedSampler order)
+            self.calls += 1
+            if rank == 1:
+                time.sleep(0.02)                  # the slow rank sets the step time
+            d, l, n = zip(*[_fake_dets(j * world + rank) for j in range(B)])
+            return (torch.from_numpy(np.stack(d)), torch.from_numpy(np.stack(l)),
+                    torch.tensor(n, dtype=torch.int32), None, None, None)
+
+    st = FakeStepper()
+    steps, warmup = 4, 2
+    elapsed = bench.timed_region(lambda: st.step(timed=True), steps, warmup, world, lambda: None,
+                                 dist.barrier, torch.device('cpu'))
+    ok = st.calls == steps + warmup
+    D, L, N = st.last[:3]
+    ok &= D.shape[0] == world * B
+    for i in range(world * B):
+        ed, el, ek = _fake_dets(i)
+        ok &= bool(np.array_equal(D[i].numpy(), ed) and np.array_equal(L[i].numpy(), el)
+                   and int(N[i]) == ek)
+    ok &= elapsed >= steps * 0.02                  # MAX over ranks: rank 0 reports rank 1's time too
+    ret[rank] = (ok, round(elapsed, 6))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_and_exchange_world2():
+    world, port = 2, _free_port()
+    ret = mp.get_context('spawn').Manager().dict()
+    mp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world)), dict(ret)
+    assert ret[0][1] == ret[1][1]                  # every rank holds the same (maximum) time
