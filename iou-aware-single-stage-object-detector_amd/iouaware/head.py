@@ -153,6 +153,18 @@ class IoUawareRetinaHead(AnchorHead):
         normal_init(self.retina_reg, std=0.01)
         normal_init(self.retina_iou, std=0.01)
 
+    train_winograd = True                 # training: all-levels Winograd convolutions when usable
+
+    def forward(self, feats):
+        """multi_apply(forward_single) of the reference (anchor_head.py:102-103); in training on a
+        ROCm device every convolution runs once for all levels on the Winograd path with its own
+        backward (iouaware/winograd_train.py) -- same parameters, same outputs to fp32 rounding."""
+        if self.training and self.train_winograd:
+            from . import winograd_train
+            if winograd_train.usable(feats, self):
+                return winograd_train.head_forward(self, feats)
+        return super(IoUawareRetinaHead, self).forward(feats)
+
     def forward_single(self, x):
         cls_feat = reg_feat = x
         for conv in self.cls_convs:

@@ -27,12 +27,17 @@ _G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
                [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
 
 
+_G_DEV = {}
+
+
 def transform_weight(w):
     """(Cout, Cin, 3, 3) conv weight -> U (36, Cin, Cout) fp32, U[6i+j] = (G g G^T)[i, j]."""
     if w.dim() != 4 or w.shape[2] != 3 or w.shape[3] != 3:
         raise ValueError('Winograd F(4,3) needs a 3x3 kernel, got %s' % (tuple(w.shape),))
     g = w.detach().to(torch.float64)
-    G = torch.from_numpy(_G).to(g.device)
+    G = _G_DEV.get(g.device)
+    if G is None:
+        G = _G_DEV[g.device] = torch.from_numpy(_G).to(g.device)
     u = torch.einsum('ik,ockl,jl->ijco', G, g, G)           # (6, 6, Cin, Cout)
     return u.reshape(36, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
 

@@ -1,0 +1,136 @@
+"""Training through the head's 3x3 convolutions on the Winograd F(4x4,3x3) path
+(BASELINE config 5: the R-50 training step; reference iou_aware_retina_head.py:171-219 for the
+convolutions, anchor_head.py / losses for what follows).
+
+The IoU-aware head is 58 % of the network's multiply-adds, and in training every one of its
+convolutions runs three times (forward, gradient w.r.t. the input, gradient w.r.t. the weights).
+MIOpen serves the first two with its F(2x2,3x3) assembly kernels, one call per level and tower
+(110 of the 139 Winograd calls of an iteration).  Here one shared-weight convolution over ALL
+pyramid levels is one autograd node:
+
+    forward     y_l = conv(x_l, w) + b  [ReLU]      in-transform -> 36 GEMMs -> out-transform
+    grad input  dx_l = conv(dy_l, w^T flipped)      the same three steps with the transposed,
+                                                    spatially flipped weight: full correlation
+                                                    = the adjoint of a stride-1 / pad-1 conv
+    grad weight sum_l wrw(x_l, dy_l)                MIOpen (aten.convolution_backward, weight and
+                                                    bias gradients only) on channels-last tensors
+
+-- the HIP transforms and the hipBLASLt batched GEMM of the inference path (winograd.py), 36
+multiplications per 4x4 output tile instead of MIOpen's 64, and all levels in one GEMM.
+Activations are channels-last fp32; the transformed weights are recomputed from the parameters
+in every call (they change every iteration).
+"""
+import torch
+
+from . import winograd as W
+
+
+def _plan(xs):
+    key = (xs[0].shape[0], tuple(tuple(x.shape[-2:]) for x in xs), xs[0].device)
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _PLANS[key] = W._Plan([tuple(x.shape[-2:]) for x in xs], xs[0].shape[0],
+                                     xs[0].device)
+    return plan
+
+
+_PLANS = {}
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) \
+        else t.contiguous(memory_format=torch.channels_last)
+
+
+def _conv_levels(plan, xs, u, bias, relu, cout, tag):
+    cin = xs[0].shape[1]
+    v = W.input_transform(plan, xs, 1, plan.buf('tv' + tag, (36, plan.T, cin)))
+    m = W.batched_gemm(v, u, plan.buf('tm' + tag, (36, plan.T, cout)))
+    ys = [torch.empty((x.shape[0], cout) + tuple(x.shape[-2:]), dtype=torch.float32,
+                      device=x.device, memory_format=torch.channels_last) for x in xs]
+    W.output_transform(plan, m, cout, 1, bias, relu, [(0, cout, ys, 0)])
+    return ys
+
+
+class _WinoConvLevels(torch.autograd.Function):
+    """conv3x3 (stride 1, pad 1) + bias (+ ReLU) with ONE weight over a list of level tensors"""
+
+    @staticmethod
+    def forward(ctx, weight, bias, relu, *xs):
+        xs = [_cl(x) for x in xs]
+        plan = _plan(xs)
+        cout = weight.shape[0]
+        with torch.no_grad():
+            u = W.transform_weight(weight)                                   # (36, Cin, Cout)
+            b = None if bias is None else bias.detach().float().contiguous()
+            ys = _conv_levels(plan, xs, u, b, relu, cout, 'f')
+        ctx.relu, ctx.has_bias, ctx.plan = bool(relu), bias is not None, plan
+        ctx.save_for_backward(weight, *xs, *(ys if relu else []))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        L = len(dys)
+        weight, xs = saved[0], list(saved[1:1 + L])
+        ys = list(saved[1 + L:]) if ctx.relu else None
+        plan = ctx.plan
+        with torch.no_grad():
+            dys = [_cl(d) for d in dys]
+            if ys is not None:                      # ReLU backward: dy where y > 0
+                dys = [torch.ops.aten.threshold_backward(d, y, 0) for d, y in zip(dys, ys)]
+            need_x = any(ctx.needs_input_grad[3 + l] for l in range(L))
+            dxs = [None] * L
+            if need_x:
+                # adjoint of correlation with w (pad 1) = correlation with w^T flipped (pad 1)
+                ut = W.transform_weight(weight.flip(2, 3).transpose(0, 1))    # (36, Cout, Cin)
+                dxs = _conv_levels(plan, dys, ut, None, False, weight.shape[1], 'b')
+            dw = db = None
+            if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
+                bsz = [weight.shape[0]] if ctx.has_bias else None
+                for x, d in zip(xs, dys):
+                    _, gw, gb = torch.ops.aten.convolution_backward(
+                        d, x, weight, bsz, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                        [False, True, ctx.has_bias])
+                    dw = gw if dw is None else dw.add_(gw)
+                    if ctx.has_bias:
+                        db = gb if db is None else db.add_(gb)
+        return (dw, db, None) + tuple(dxs)
+
+
+def wino_conv_levels(xs, weight, bias=None, relu=False):
+    """xs: list of (B, Cin, H_l, W_l) fp32 CUDA tensors; -> list of (B, Cout, H_l, W_l)
+    channels-last tensors.  Cin and Cout must be multiples of 4."""
+    return list(_WinoConvLevels.apply(weight, bias, relu, *xs))
+
+
+def usable(feats, head):
+    return (torch.is_grad_enabled() and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                                            for x in feats)
+            and head.in_channels % 4 == 0 and head.feat_channels % 4 == 0
+            and (head.num_anchors * head.cls_out_channels) % 4 == 0
+            and all(not m.with_norm and m.with_activatation
+                    for m in list(head.cls_convs) + list(head.reg_convs)))
+
+
+def head_forward(head, feats):
+    """IoUawareRetinaHead.forward (multi_apply(forward_single), reference :171-219) with every
+    convolution evaluated for all levels at once.  Returns (cls[L], reg[L], iou[L]); reg / iou are
+    channel slices of one 48-channel output (retina_reg | retina_iou | zero padding)."""
+    cls_feat = reg_feat = [_cl(x) for x in feats]
+    for conv in head.cls_convs:
+        cls_feat = wino_conv_levels(cls_feat, conv.conv.weight, conv.conv.bias, relu=True)
+    for conv in head.reg_convs:
+        reg_feat = wino_conv_levels(reg_feat, conv.conv.weight, conv.conv.bias, relu=True)
+    cls = wino_conv_levels(cls_feat, head.retina_cls.weight, head.retina_cls.bias)
+    n_reg, n_iou = head.retina_reg.out_channels, head.retina_iou.out_channels
+    pad = (-(n_reg + n_iou)) % 4
+    w_ri = torch.cat([head.retina_reg.weight, head.retina_iou.weight] +
+                     ([head.retina_reg.weight.new_zeros((pad,) + tuple(head.retina_reg.weight.shape[1:]))]
+                      if pad else []))
+    b_ri = torch.cat([head.retina_reg.bias, head.retina_iou.bias] +
+                     ([head.retina_reg.bias.new_zeros(pad)] if pad else []))
+    ri = wino_conv_levels(reg_feat, w_ri, b_ri)
+    reg = [t[:, :n_reg] for t in ri]
+    iou = [t[:, n_reg:n_reg + n_iou] for t in ri]
+    return cls, reg, iou
