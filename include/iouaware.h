@@ -228,6 +228,13 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
                              const float *bias, int relu, int nseg, const ia_wino_seg *segs,
                              void *stream);
 
+/* Training: gradient of the output transform, dM = A dY A^T per tile (dY (B,H,W,channels)
+ * channels-last per level, zero outside the map), written as 36 matrices (36, tiles, channels)
+ * like V -- the right-hand operand of the Winograd-domain weight gradient
+ * dU[k] = V[k]^T dM[k]  (then dW = G^T dU G on the host side).                          */
+int ia_wino_grad_output_transform(const ia_wino_geom *g, const float *const *dy, int channels,
+                                  float *dM, void *stream);
+
 /* 1x1 convolution on a channels-last activation as one library GEMM (hipBLASLt) with the folded
  * BatchNorm bias, the residual and the ReLU in its epilogue (Bottleneck.forward,
  * mmdet/models/backbones/resnet.py:215-255, at inference):

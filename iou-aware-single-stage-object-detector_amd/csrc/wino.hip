@@ -215,6 +215,66 @@ __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
     }
 }
 
+// one line of A dy: the adjoint of at6 (4 values -> 6), A = (A^T)^T
+__device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&o)[6])
+{
+    const float4 s02 = y[0] + y[2], s13 = y[1] + y[3];
+    const float4 t02 = y[0] + 4.0f * y[2], t13 = 2.0f * y[1] + 8.0f * y[3];
+    o[0] = y[0];
+    o[1] = s02 + s13;
+    o[2] = s02 - s13;
+    o[3] = t02 + t13;
+    o[4] = t02 - t13;
+    o[5] = y[3];
+}
+
+// Gradient of the output transform (training, weight gradient in the Winograd domain):
+// dM = A dY A^T per tile, dY = the 4x4 output pixels of the tile (zero outside the feature map,
+// where the forward output transform wrote nothing), scattered as 36 matrices like V.
+__global__ void __launch_bounds__(64) k_wino_dy(WinoInArgs a)
+{
+    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    if (!lm.on) return;
+    const int t = lm.t, c = lm.c;
+    const TileRef r = locate_tile(a.lv, t);
+    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
+    const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
+    float4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = r.y0 + i;
+        const int yc = (y < H) ? y : (H - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = r.x0 + j;
+            const int xc = (xx < W) ? xx : (W - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
+            d[i][j] = (y < H && xx < W) ? v : f4(0.0f);
+        }
+    }
+    float4 tmp[6][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                       // columns: tmp = A d
+        float4 col[4], o[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[i] = d[i][j];
+        a6(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = o[i];
+    }
+    const int g = c / a.Cg, cc = c - g * a.Cg;
+    float *v = a.V + ((size_t)g * 36 * a.T + t) * a.Cg + cc;
+    const size_t kstride = (size_t)a.T * a.Cg;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {                       // rows: dM = tmp A^T
+        float4 o[6];
+        a6(tmp[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            *reinterpret_cast<float4 *>(v + (size_t)(i * 6 + j) * kstride) = o[j];
+    }
+}
+
 constexpr int kMaxSeg = 4;
 
 struct WinoSeg {                          // output channels [c0, c0 + n) -> dst tensors with Cdst channels
@@ -333,6 +393,27 @@ int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int ch
     const int waves = (a.T + a.tpw - 1) / a.tpw;
     dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
     hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
+
+int ia_wino_grad_output_transform(const ia_wino_geom *g, const float *const *dy, int channels,
+                                   float *dM, void *stream)
+{
+    ia::WinoInArgs a;
+    int rc = ia::make_wino_levels(g, a.lv);
+    if (rc) return rc;
+    if (!dy || !dM || channels < 4 || (channels & 3)) return IA_E_ARG;
+    a.Ctot = channels; a.Cg = channels; a.T = a.lv.tile_off[a.lv.L];
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        a.x[l] = (l < a.lv.L) ? dy[l] : nullptr;
+        if (l < a.lv.L && (!dy[l] || ((uintptr_t)dy[l] & 15u))) return IA_E_ARG;
+    }
+    a.V = dM;
+    a.pre_scale = a.pre_shift = nullptr; a.pre_relu = 0;
+    a.tpw = ia::tiles_per_wave(channels);
+    const int waves = (a.T + a.tpw - 1) / a.tpw;
+    dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
+    hipLaunchKernelGGL(ia::k_wino_dy, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     'ia_wino_tiles': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_int32)]),
     'ia_wino_input_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _i, _vp, _vp, _i,
                                      _vp, _vp]),
+    'ia_wino_grad_output_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _vp, _vp]),
     'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
                                       C.POINTER(WinoSeg), _vp]),
     'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),

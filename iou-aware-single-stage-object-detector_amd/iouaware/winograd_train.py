@@ -12,8 +12,13 @@ pyramid levels is one autograd node:
     grad input  dx_l = conv(dy_l, w^T flipped)      the same three steps with the transposed,
                                                     spatially flipped weight: full correlation
                                                     = the adjoint of a stride-1 / pad-1 conv
-    grad weight sum_l wrw(x_l, dy_l)                MIOpen (aten.convolution_backward, weight and
-                                                    bias gradients only) on channels-last tensors
+    grad weight dU[k] = V[k]^T dM[k], dW = G^T dU G  in the Winograd domain: V = B^T x B is kept
+                                                    from the forward pass, dM = A dy A^T is one
+                                                    more HIP transform (k_wino_dy), the 36
+                                                    (Cin x tiles) x (tiles x Cout) products are one
+                                                    batched library GEMM -- instead of one MIOpen
+                                                    wrw call per level (17 of the 59 ms of an
+                                                    iteration before)
 
 -- the HIP transforms and the hipBLASLt batched GEMM of the inference path (winograd.py), 36
 multiplications per 4x4 output tile instead of MIOpen's 64, and all levels in one GEMM.
@@ -42,14 +47,39 @@ def _cl(t):
         else t.contiguous(memory_format=torch.channels_last)
 
 
-def _conv_levels(plan, xs, u, bias, relu, cout, tag):
+def _conv_levels(plan, xs, u, bias, relu, cout, tag, keep_v=False):
     cin = xs[0].shape[1]
-    v = W.input_transform(plan, xs, 1, plan.buf('tv' + tag, (36, plan.T, cin)))
+    vbuf = torch.empty((36, plan.T, cin), dtype=torch.float32, device=xs[0].device) if keep_v \
+        else plan.buf('tv' + tag, (36, plan.T, cin))
+    v = W.input_transform(plan, xs, 1, vbuf)
     m = W.batched_gemm(v, u, plan.buf('tm' + tag, (36, plan.T, cout)))
     ys = [torch.empty((x.shape[0], cout) + tuple(x.shape[-2:]), dtype=torch.float32,
                       device=x.device, memory_format=torch.channels_last) for x in xs]
     W.output_transform(plan, m, cout, 1, bias, relu, [(0, cout, ys, 0)])
-    return ys
+    return (ys, v) if keep_v else ys
+
+
+def grad_output_transform(plan, dys, out):
+    """dM = A dY A^T of every tile -> (36, T, Cout)"""
+    import ctypes as C
+    from . import _lib
+    from .ops import _ptr, _stream
+    ptrs = (C.c_void_p * len(dys))(*[d.data_ptr() for d in dys])
+    ch = int(dys[0].shape[1])
+    W._timed('dy', plan.T * ch * 4 * (16 + 36), lambda: _lib.check(
+        _lib.lib().ia_wino_grad_output_transform(C.byref(plan.geom), ptrs, ch, _ptr(out),
+                                                 _stream()), 'ia_wino_grad_output_transform'))
+    return out
+
+
+def untransform_weight_grad(du):
+    """(36, Cin, Cout) gradient w.r.t. U = G g G^T  ->  (Cout, Cin, 3, 3) gradient w.r.t. g"""
+    G = W._G_DEV.get(du.device)
+    if G is None:
+        G = W._G_DEV[du.device] = torch.from_numpy(W._G).to(du.device)
+    cin, cout = du.shape[1], du.shape[2]
+    d6 = du.reshape(6, 6, cin, cout).to(torch.float64)
+    return torch.einsum('ik,ijco,jl->ockl', G, d6, G).to(torch.float32)
 
 
 class _WinoConvLevels(torch.autograd.Function):
@@ -63,17 +93,22 @@ class _WinoConvLevels(torch.autograd.Function):
         with torch.no_grad():
             u = W.transform_weight(weight)                                   # (36, Cin, Cout)
             b = None if bias is None else bias.detach().float().contiguous()
-            ys = _conv_levels(plan, xs, u, b, relu, cout, 'f')
-        ctx.relu, ctx.has_bias, ctx.plan = bool(relu), bias is not None, plan
-        ctx.save_for_backward(weight, *xs, *(ys if relu else []))
+            keep = weight.requires_grad
+            out = _conv_levels(plan, xs, u, b, relu, cout, 'f', keep_v=keep)
+            ys, v = out if keep else (out, None)
+        ctx.relu, ctx.has_bias, ctx.plan, ctx.L = bool(relu), bias is not None, plan, len(xs)
+        # V (the transformed input) replaces the input itself: it is what the Winograd-domain
+        # weight gradient multiplies, and nothing else of x is needed in backward
+        ctx.save_for_backward(weight, *(ys if relu else []), *([v] if keep else []))
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         saved = ctx.saved_tensors
-        L = len(dys)
-        weight, xs = saved[0], list(saved[1:1 + L])
-        ys = list(saved[1 + L:]) if ctx.relu else None
+        L = ctx.L
+        weight = saved[0]
+        ys = list(saved[1:1 + L]) if ctx.relu else None
+        v = saved[-1] if (len(saved) > 1 + (L if ctx.relu else 0)) else None
         plan = ctx.plan
         with torch.no_grad():
             dys = [_cl(d) for d in dys]
@@ -86,15 +121,13 @@ class _WinoConvLevels(torch.autograd.Function):
                 ut = W.transform_weight(weight.flip(2, 3).transpose(0, 1))    # (36, Cout, Cin)
                 dxs = _conv_levels(plan, dys, ut, None, False, weight.shape[1], 'b')
             dw = db = None
-            if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
-                bsz = [weight.shape[0]] if ctx.has_bias else None
-                for x, d in zip(xs, dys):
-                    _, gw, gb = torch.ops.aten.convolution_backward(
-                        d, x, weight, bsz, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                        [False, True, ctx.has_bias])
-                    dw = gw if dw is None else dw.add_(gw)
-                    if ctx.has_bias:
-                        db = gb if db is None else db.add_(gb)
+            if ctx.needs_input_grad[0] and v is not None:
+                cout = weight.shape[0]
+                dm = grad_output_transform(plan, dys, plan.buf('tdm', (36, plan.T, cout)))
+                du = torch.bmm(v.transpose(1, 2), dm)                         # (36, Cin, Cout)
+                dw = untransform_weight_grad(du)
+            if ctx.has_bias and ctx.needs_input_grad[1]:
+                db = sum(d.sum((0, 2, 3)) for d in dys)
         return (dw, db, None) + tuple(dxs)
 
 
