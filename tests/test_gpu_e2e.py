@@ -213,8 +213,10 @@ def test_reference_call_signature_variants(golden_dir):
     for a, b in zip(r0, r1):
         assert a.shape == b.shape and G.close(a, b, TOL)
     sf = float(f['scale_factor'])
-    cat0, cat2 = np.concatenate(r0), np.concatenate(r2)
-    assert cat0.shape == cat2.shape and G.close(cat0[:, :4] * sf, cat2[:, :4], TOL)
+    # set-wise (two detections of a class with scores 1e-6 apart may swap between two forwards)
+    scaled = [np.concatenate([a[:, :4] * sf, a[:, 4:]], 1) for a in r0]
+    matched, total, _, _ = _match_sets(scaled, r2)
+    assert total == 100 and matched >= total - 1, (matched, total)
     # batch of two through the same entry point: a list of per-image results
     with torch.no_grad():
         two = m(return_loss=False, rescale=True, img=[torch.cat([x, x])], img_meta=[[meta, meta]])
