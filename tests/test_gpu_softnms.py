@@ -1,7 +1,7 @@
 """GPU (MI355X): soft-NMS kernels (csrc/softnms.hip) through the C-ABI against the oracle -- bit
-for bit (selection order, indices, decayed scores, both methods, discards, ties) -- against the
-reference-generated fixture, and, when oracle/_ref/soft_nms_cpu.so travelled with the snapshot,
-against the reference's own module."""
+for bit (selection order, indices, decayed scores, both methods, discards, ties) -- and against the
+reference-generated fixture tests/golden/soft_nms.npz.  (The oracle is compared with the
+reference's own Cython module in the build container, tests/test_oracle_softnms.py.)"""
 import os
 
 import numpy as np
@@ -65,9 +65,10 @@ def test_soft_nms_op_golden(ops, golden_dir):
     assert e.shape == (0, 5) and ei.shape == (0,)
 
 
-def test_soft_nms_op_random_vs_oracle_and_reference(ops, oracle_lib):
-    import build_ref
-    ref = build_ref.load_soft()
+def test_soft_nms_op_random_vs_oracle(ops, oracle_lib):
+    """HIP vs the oracle on random / tie-heavy cases.  The oracle itself is compared with the
+    reference's own Cython module in the BUILD CONTAINER only (tests/test_oracle_softnms.py);
+    on the GPU box the reference is represented by the committed fixture soft_nms.npz above."""
     rs = np.random.RandomState(6)
     sizes = [1, 2, 63, 64, 65, 255, 256, 257, 700, 2100, 4693]
     for trial, n in enumerate(sizes * 2):
@@ -80,9 +81,6 @@ def test_soft_nms_op_random_vs_oracle_and_reference(ops, oracle_lib):
             ob, oi = oracle_lib.soft_nms(d, thr, method, sigma, ms)
             assert np.array_equal(inds.cpu().numpy(), oi), (n, method, trial)
             assert G.same_bits(nd.cpu().numpy(), ob), (n, method, trial)
-            if ref is not None and n <= 700:
-                rb, ri = ref.soft_nms_cpu(d.copy(), thr, method=code, sigma=sigma, min_score=ms)
-                assert np.array_equal(ri, oi) and G.same_bits(rb.astype(np.float32), ob)
 
 
 def _soft_oracle(oracle_lib, cls, reg, iou, b, base, img_hw, sf, nms_pre, score_thr, kw, mp):
