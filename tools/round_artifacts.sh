@@ -1,0 +1,21 @@
+#!/bin/bash
+# everything profiles/ keeps for a round, in one gpurun call (about 10 GPU-minutes)
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/round
+mkdir -p $OUT
+bash $ROOT/tools/profile_bench.sh > $OUT/profile_bench.log 2>&1
+cp $ROOT/gpurun_out/profile/bench.json $OUT/bench_profiled_run.json
+cp $ROOT/gpurun_out/profile/step_summary.txt $OUT/bench_step_summary.txt
+cp $ROOT/gpurun_out/profile/kernel_stats_ia.csv $OUT/bench_kernel_stats_ia.csv
+cp $ROOT/gpurun_out/profile/kernel_stats.csv $OUT/bench_kernel_stats_top60.csv
+cp $ROOT/gpurun_out/profile/head_pmc.json $OUT/head_pmc.json
+bash $ROOT/tools/collect_mfma_pmc.sh > $OUT/mfma_pmc.log 2>&1
+cp $ROOT/gpurun_out/pmc/mfma_pmc.json $OUT/mfma_pmc.json
+bash $ROOT/tools/profile_headloss.sh > $OUT/profile_headloss.log 2>&1
+cp $ROOT/gpurun_out/profile/train_loss_part_all.txt $OUT/train_loss_part_summary.txt
+cp $ROOT/gpurun_out/profile/train_loss_part_per_level.txt $OUT/train_loss_part_per_level_kernels.txt
+bash $ROOT/tools/profile_train.sh > $OUT/profile_train.log 2>&1
+cp $ROOT/gpurun_out/profile/train_step_summary.txt $OUT/train_step_summary.txt
+python $ROOT/tools/try_configs.py > $OUT/other_configs.txt 2>&1
+cd $ROOT && python bench.py > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+tail -3 $OUT/other_configs.txt; cut -c1-400 $OUT/bench_default_run.json
