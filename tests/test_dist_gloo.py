@@ -173,3 +173,51 @@ def test_bench_timed_region_and_exchange_world2():
     mp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world)), dict(ret)
     assert ret[0][1] == ret[1][1]                  # every rank holds the same (maximum) time
+
+
+def _none_loss_worker(rank, world, port, ret):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from iouaware import dist as idist
+    from iouaware.train import train_step
+    idist.init_dist('pytorch', backend='gloo')
+
+    class NoLoss(torch.nn.Module):                 # head.loss returned None (reference :362-363)
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+        def forward(self, img, img_meta, return_loss=True, **kw):
+            return None
+    net = NoLoss()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    try:
+        train_step(net, opt, torch.zeros(1, 3, 8, 8), [{}], [None], [None], allreduce=True)
+        ret[rank] = 'returned'
+    except RuntimeError as exc:
+        ret[rank] = 'raised' if 'distributed step' in str(exc) else 'other: %s' % exc
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_none_loss_raises_instead_of_hanging_the_collective():
+    """returning early on one rank would leave the others blocked in the all-reduce"""
+    world, port = 2, _free_port()
+    ret = mp.get_context('spawn').Manager().dict()
+    mp.spawn(_none_loss_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 'raised', 1: 'raised'}
+    # single process: None propagates like in the reference's runner
+    sys.path.insert(0, PKG)
+    from iouaware.train import train_step
+
+    class NoLoss(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+        def forward(self, img, img_meta, return_loss=True, **kw):
+            return None
+    net = NoLoss()
+    assert train_step(net, torch.optim.SGD(net.parameters(), lr=0.1), torch.zeros(1, 3, 8, 8),
+                      [{}], [None], [None]) is None

@@ -353,3 +353,21 @@ def test_channels_last_other_class_counts(ops, oracle_lib, Cn, dtype):
         assert np.array_equal(labels[b, :n].cpu().numpy(), o['det_labels'])
         assert np.array_equal(rows[b, :n].cpu().numpy(), o['det_rows'])
         assert G.same_bits(dets[b, :n].cpu().numpy(), o['det_bboxes'])
+
+
+def test_multiclass_nms_wrapper_max_num_minus_one_quirk(ops):
+    """bbox_nms.py:52-56 with the default max_num=-1: `shape[0] > -1` is always true, the
+    survivors are sorted by score and `inds[:-1]` drops the lowest one"""
+    from iouaware import nms_op
+    rs = np.random.RandomState(3)
+    n = 300
+    xy = rs.uniform(0, 400, (n, 2))
+    boxes = torch.from_numpy(np.concatenate([xy, xy + rs.uniform(8, 80, (n, 2))], 1).astype(np.float32)).cuda()
+    sc = rs.uniform(0, 1, (n, 4)).astype(np.float32)
+    sc[:, 0] = 0
+    scores = torch.from_numpy(sc).cuda()
+    cfg = dict(type='nms', iou_thr=0.5)
+    full_b, full_l = nms_op.multiclass_nms(boxes, scores, 0.3, cfg, 1024)
+    quirk_b, quirk_l = nms_op.multiclass_nms(boxes, scores, 0.3, cfg)          # max_num = -1
+    assert full_b.shape[0] > 10 and quirk_b.shape[0] == full_b.shape[0] - 1
+    assert torch.equal(quirk_b, full_b[:-1]) and torch.equal(quirk_l, full_l[:-1])

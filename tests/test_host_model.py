@@ -174,3 +174,39 @@ def test_reference_configs_load_unchanged_and_convs_match():
     for ta, tb in zip(a, b):
         for u, v in zip(ta, tb):
             assert torch.equal(u, v)
+
+
+class _Opaque(object):
+    """an arbitrary Python object inside a checkpoint: what the safe unpickler refuses"""
+
+
+def test_checkpoint_loads_with_the_safe_unpickler_by_default(tmp_path):
+    """reference checkpoints are tensors + a plain meta dict; anything else needs an
+    explicit opt-in"""
+    from iouaware import checkpoint
+    m = iouaware.build_detector(model_cfg(), test_cfg=ConfigDict(TEST_CFG))
+    sd = {'module.' + k: v + 1 for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    good = str(tmp_path / 'good.pth')
+    torch.save(dict(state_dict=sd, meta=dict(epoch=12, iter=7, mmdet_version='0.6.0')), good)
+    ck = checkpoint.load_checkpoint(m, good)
+    assert ck['meta']['epoch'] == 12
+    k0 = 'backbone.conv1.weight'
+    assert torch.equal(m.state_dict()[k0], sd['module.' + k0])            # 'module.' stripped
+
+    bad = str(tmp_path / 'bad.pth')
+    torch.save(dict(state_dict=sd, meta=dict(obj=_Opaque())), bad)
+    with pytest.raises(Exception):
+        checkpoint.load_checkpoint(m, bad)
+    assert checkpoint.load_checkpoint(m, bad, allow_pickle=True)['meta']['obj'] is not None
+
+
+def test_multiclass_nms_wrapper_validates_its_limits():
+    """explicit errors instead of the C ABI's generic 'argument error'"""
+    from iouaware import nms_op, _lib
+    cfg = dict(type='nms', iou_thr=0.5)
+    with pytest.raises(ValueError, match='at most'):
+        nms_op.multiclass_nms(torch.zeros(_lib.IA_MAX_CANDIDATES + 1, 4),
+                              torch.zeros(_lib.IA_MAX_CANDIDATES + 1, 3), 0.05, cfg, 100)
+    with pytest.raises(ValueError, match='max_num'):
+        nms_op.multiclass_nms(torch.zeros(8, 4), torch.zeros(8, 3), 0.05, cfg,
+                              _lib.IA_MAX_PER_IMG + 1)
