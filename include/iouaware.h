@@ -396,6 +396,19 @@ int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, i
                      const float *result, const float *grad_result, const ia_level_ptrs *grads,
                      void *stream);
 
+/* ------------------------------------------------------------------ ResNeXt grouped 3x3 convolution
+ * conv2 of the ResNeXt bottleneck (mmdet/models/backbones/resnext.py:12-91: groups = 32 / 64,
+ * 4 / 8 / 16 / 32 channels per group), channels-last fp32, pad 1, stride 1 or 2, + per-channel
+ * bias (the folded BatchNorm shift) + optional ReLU, on v_mfma_f32_16x16x4_f32.
+ * ia_grouped_conv3x3_pack is HOST code: weight (C, C/groups, 3, 3) and optional per-output-channel
+ * scale (folded BatchNorm scale) -> wpack, C/16 * 9 * 16 * 64 floats for <= 16 channels per
+ * group, C/32 * 9 * 64 * 64 for 32 (host pointers); copy wpack to the device once.        */
+int ia_grouped_conv3x3_pack(const float *weight, const float *scale, int channels, int groups,
+                            float *wpack);
+int ia_grouped_conv3x3_nhwc(const float *x, const float *wpack, const float *bias, float *y,
+                            int batch, int H, int W, int channels, int groups, int stride, int relu,
+                            void *stream);
+
 /* mmdet.ops.sigmoid_focal_loss: sigmoid_focal_loss_cuda.forward / .backward
  * (mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_cuda.cu:23-63,65-105;
  * binding sigmoid_focal_loss.cpp:17-43).  logits (N,C) fp32, targets (N) int64,

@@ -125,6 +125,8 @@ SIGNATURES = {
                               _sz, _vp, _vp]),
     'ia_head_loss_bwd': (_i, [_G, _P, _i, _i, C.POINTER(HeadTargets), C.POINTER(HeadLossCfg), _vp,
                               _vp, _vp, _P, _vp]),
+    'ia_grouped_conv3x3_pack': (_i, [_vp, _vp, _i, _i, _vp]),
+    'ia_grouped_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_channel_affine_act': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),

@@ -84,8 +84,16 @@ def _bottleneck_forward(self, x):
         out, pre = ops.linear_bias_act(x, w['w1'], f['b1'], relu=True), None
     else:
         out, pre = self.conv1(x), (f['s1'], f['b1'], True)
+    gw = f.get('gconv2')
     wino = f.get('wino2')
-    if wino is not None and wino.usable(out):
+    if gw is not None and out.dtype == torch.float32 \
+            and out.is_contiguous(memory_format=torch.channels_last):
+        # ResNeXt: grouped 3x3 conv2 + folded BN + ReLU on the MFMA kernel of csrc/gconv.hip
+        if pre is not None:
+            out = ops.channel_affine_act_(out, f['s1'], f['b1'], relu=True)
+        out = ops.grouped_conv3x3(out, gw, f['b2'], self.conv2.groups, self.conv2.stride[0],
+                                  relu=True)
+    elif wino is not None and wino.usable(out):
         # (conv1's BN + ReLU on load,) conv2 + its folded BN + ReLU in the Winograd path
         out = wino(out, pre=pre)
     else:
@@ -264,6 +272,14 @@ def _fold(m):
                     else:
                         f['wd_conv'] = (ds.weight.float() * f['sd'].view(-1, 1, 1, 1)).contiguous(
                             memory_format=torch.channels_last)
+        c2 = m.conv2
+        if winograd and c2.groups > 1 and tuple(c2.kernel_size) == (3, 3) \
+                and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) \
+                and c2.stride[0] == c2.stride[1] and c2.stride[0] in (1, 2) and c2.bias is None \
+                and c2.in_channels == c2.out_channels \
+                and c2.in_channels // c2.groups in (4, 8, 16, 32) \
+                and c2.in_channels % (32 if c2.in_channels // c2.groups == 32 else 16) == 0:
+            f['gconv2'] = ops.pack_grouped_weight(c2.weight, f['s2'])     # BN scale folded in
         if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
             from .winograd import WinogradConv3x3
             with torch.no_grad():           # BN scale folded into the weights, shift = bias

@@ -475,6 +475,37 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False):
     return out
 
 
+def pack_grouped_weight(weight, scale=None):
+    """(C, C/groups, 3, 3) grouped conv weight (+ per-output-channel scale) -> the per-lane MFMA
+    operand layout of csrc/gconv.hip, on the weight's device.  Host-side arrangement (once per
+    fuse), through the C-ABI helper."""
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    Cn, cg = int(w.shape[0]), int(w.shape[1])
+    groups = Cn // cg
+    nb = 2 if cg == 32 else 1
+    out = torch.empty(Cn // (16 * nb) * 9 * nb * 4 * nb * 64, dtype=torch.float32)
+    sc = None if scale is None else scale.detach().to('cpu', torch.float32).contiguous()
+    _lib.check(_lib.lib().ia_grouped_conv3x3_pack(w.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                  Cn, groups, out.data_ptr()),
+               'ia_grouped_conv3x3_pack')
+    return out.to(weight.device)
+
+
+def grouped_conv3x3(x, wpack, bias, groups, stride=1, relu=False):
+    """channels-last fp32 (B, C, H, W) -> (B, C, Ho, Wo), grouped 3x3 / pad 1 conv + bias (+ReLU)"""
+    _require_gpu(x, 'x')
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('grouped_conv3x3 needs a channels-last fp32 tensor')
+    B, Cn, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cn, Ho, Wo), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    _lib.check(_lib.lib().ia_grouped_conv3x3_nhwc(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(y), B, H, W,
+                                                  Cn, int(groups), int(stride), int(bool(relu)),
+                                                  _stream()), 'ia_grouped_conv3x3_nhwc')
+    return y
+
+
 def test_math(op, x, y=None):
     _require_gpu(x, 'x')
     x = x.contiguous()

@@ -262,8 +262,9 @@ def _trained_like(m, seed=11):
     ('x101_32x4d', dict(type='ResNeXt', depth=101, groups=32, base_width=4)),
 ])
 def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
-    """R-101 (config 3's backbone) and X-101-64x4d (config 4; grouped 3x3 convs stay on MIOpen,
-    reference resnext.py:12-91): fused and Winograd paths vs the module forward, 1e-4."""
+    """R-101 (config 3's backbone) and X-101-64x4d (config 4; its grouped 3x3 convs run on the
+    MFMA kernel of csrc/gconv.hip in the channels-last path, reference resnext.py:12-91): fused
+    and Winograd paths vs the module forward, 1e-4."""
     from iouaware.fuse import fuse_inference, unfuse_inference
     m = _trained_like(_build(backbone)).cuda()
     x = torch.from_numpy(synth.e2e_image(9, 2, 256, 320, 256, 320)).cuda()
@@ -281,7 +282,7 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
         wino_dets = m.simple_test_batch(xc, metas, rescale=True)
         grouped = [b for b in m.backbone.modules() if hasattr(b, 'conv2') and b.conv2.groups > 1]
         assert (len(grouped) > 0) == name.startswith('x101')
-        assert all('wino2' not in b._ia_fused for b in grouped)       # grouped conv2 -> MIOpen
+        assert all('wino2' not in b._ia_fused and 'gconv2' in b._ia_fused for b in grouped)
     for tag, out in (('fused', fused), ('winograd', wino)):
         for a, b in zip(ref, out):
             for u, v in zip(a, b):
