@@ -17,12 +17,52 @@
 //   * exact fp32 (the f32 MFMA is a k-ordered fmaf chain), 36 MFMAs per 16 pixels x 16 channels.
 // Block-diagonal zero padding wastes MFMA work for Cg = 4 / 8 (4x / 2x), which these layers can
 // afford: their cost is the activation traffic.
+// MI355X, batch 8 (rocprofv3, X-101-64x4d): layer1 520 us, layer2 275, layer3 153, layer4 140 per
+// convolution -- CK: 1300 / 650 / 230 / 230; about half of the f32 MFMA issue rate.  Measured and
+// not adopted: an XCD-contiguous row mapping (no change), 2 - 4 independent accumulator chains
+// (no change: five wavefronts per SIMD already hide the 40-cycle dependent latency), several rows
+// per wavefront to amortise the operand loads (no change).
 #include <string.h>
 #include "ia_internal.hpp"
 
 namespace ia {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Lanes are (pixel i = lane & 15, channel quad kk = lane >> 4): a DPP row holds the 16 pixels of
+// one quad.  value of pixel i-1: row_shr:1 of the centre, lane 0 from the previous tile's lane 15
+// (row_ror:1 of it); value of pixel i+1: row_shl:1, lane 15 from the next tile's lane 0
+// (row_ror:15 of it).  Lanes without a DPP source keep `old` (bound_ctrl = 0).
+__device__ __forceinline__ float dpp_shr1(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        __builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_shl1(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        __builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x101, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror(float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f32x4 shift_from_left(const f32x4 &c, const f32x4 &prev)
+{
+    f32x4 o;
+    o.x = dpp_shr1(dpp_ror<0x121>(prev.x), c.x); o.y = dpp_shr1(dpp_ror<0x121>(prev.y), c.y);
+    o.z = dpp_shr1(dpp_ror<0x121>(prev.z), c.z); o.w = dpp_shr1(dpp_ror<0x121>(prev.w), c.w);
+    return o;
+}
+__device__ __forceinline__ f32x4 shift_from_right(const f32x4 &c, const f32x4 &next)
+{
+    f32x4 o;
+    o.x = dpp_shl1(dpp_ror<0x12F>(next.x), c.x); o.y = dpp_shl1(dpp_ror<0x12F>(next.y), c.y);
+    o.z = dpp_shl1(dpp_ror<0x12F>(next.z), c.z); o.w = dpp_shl1(dpp_ror<0x12F>(next.w), c.w);
+    return o;
+}
 
 struct GConvArgs {
     const float *x;            // (B, H, W, C) channels-last
@@ -63,22 +103,65 @@ __global__ void __launch_bounds__(256) k_gconv3x3(GConvArgs a)
     const float *xb = a.x + (size_t)b * a.H * a.W * a.C + cbase + 4 * kk;
     float *yb = a.y + ((size_t)b * a.Ho + yo) * a.Wo * a.C + cbase + i;
     const int tiles = (a.Wo + 15) / 16;
-    for (int tile = 0; tile < tiles; ++tile) {
-        const int xo = tile * 16 + i;                  // this lane's A-operand pixel
-        f32x4 v[9][NB];
+    // stride 1: the three horizontal taps of a row are the same 16 pixels shifted by one lane.
+    // One load per input row and tile instead of three (every load touches 16 half-used cache
+    // lines; with nine loads per tile the kernel ran at 85 cycles per MFMA, with three at 75):
+    // the dx = -1 / +1 operands come from the centre registers by DPP row shifts, the tile's edge
+    // lanes from the previous / next tile's centre (rotated into place), which is prefetched one
+    // tile ahead.
+    f32x4 prv[3][NB], cur[3][NB], nxt[3][NB];
+    auto load_rows = [&](int tile, f32x4 (&dst)[3][NB]) {
+        const int xo = tile * 16 + i;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {                  // all loads of the tile first
-            const int yi = yo * STRIDE + t / 3 - 1;
-            const int xi = xo * STRIDE + t % 3 - 1;
-            const bool in = (yi >= 0) && (yi < a.H) && (xi >= 0) && (xi < a.W) && (xo < a.Wo);
+        for (int r = 0; r < 3; ++r) {
+            const int yi = yo + r - 1;
+            const bool in = (yi >= 0) && (yi < a.H) && (xo < a.W) && (tile < tiles);
             const int yc = (yi < 0) ? 0 : ((yi >= a.H) ? a.H - 1 : yi);
-            const int xc = (xi < 0) ? 0 : ((xi >= a.W) ? a.W - 1 : xi);
+            const int xc = (xo >= a.W) ? a.W - 1 : xo;
             const float *p = xb + ((size_t)yc * a.W + xc) * a.C;
 #pragma unroll
             for (int ci = 0; ci < NB; ++ci) {
                 const f32x4 q = *reinterpret_cast<const f32x4 *>(p + 16 * ci);   // unconditional
                 f32x4 z; z.x = z.y = z.z = z.w = 0.0f;
-                v[t][ci] = in ? q : z;
+                dst[r][ci] = in ? q : z;
+            }
+        }
+    };
+    if (STRIDE == 1) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int ci = 0; ci < NB; ++ci) prv[r][ci].x = prv[r][ci].y = prv[r][ci].z = prv[r][ci].w = 0.0f;
+        load_rows(0, cur);
+    }
+    for (int tile = 0; tile < tiles; ++tile) {
+        f32x4 v[9][NB];
+        if (STRIDE == 1) {
+            load_rows(tile + 1, nxt);                  // zeros beyond the last tile
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int ci = 0; ci < NB; ++ci) {
+                    v[3 * r + 1][ci] = cur[r][ci];
+                    v[3 * r + 0][ci] = shift_from_left(cur[r][ci], prv[r][ci]);
+                    v[3 * r + 2][ci] = shift_from_right(cur[r][ci], nxt[r][ci]);
+                }
+        } else {
+            const int xo = tile * 16 + i;              // this lane's A-operand pixel
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {              // all loads of the tile first
+                const int yi = yo * STRIDE + t / 3 - 1;
+                const int xi = xo * STRIDE + t % 3 - 1;
+                const bool in = (yi >= 0) && (yi < a.H) && (xi >= 0) && (xi < a.W) && (xo < a.Wo);
+                const int yc = (yi < 0) ? 0 : ((yi >= a.H) ? a.H - 1 : yi);
+                const int xc = (xi < 0) ? 0 : ((xi >= a.W) ? a.W - 1 : xi);
+                const float *p = xb + ((size_t)yc * a.W + xc) * a.C;
+#pragma unroll
+                for (int ci = 0; ci < NB; ++ci) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(p + 16 * ci);   // unconditional
+                    f32x4 z; z.x = z.y = z.z = z.w = 0.0f;
+                    v[t][ci] = in ? q : z;
+                }
             }
         }
         f32x4 acc[NB];
@@ -107,6 +190,12 @@ __global__ void __launch_bounds__(256) k_gconv3x3(GConvArgs a)
                 if (a.relu) val = (val > 0.0f) ? val : 0.0f;
                 if (px < a.Wo) yb[(size_t)px * a.C + 16 * co] = val;
             }
+        }
+        if (STRIDE == 1) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int ci = 0; ci < NB; ++ci) { prv[r][ci] = cur[r][ci]; cur[r][ci] = nxt[r][ci]; }
         }
     }
 }
