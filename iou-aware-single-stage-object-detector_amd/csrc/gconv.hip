@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(256) k_gconv3x3(GConvArgs a)
     // lines; with nine loads per tile the kernel ran at 85 cycles per MFMA, with three at 75):
     // the dx = -1 / +1 operands come from the centre registers by DPP row shifts, the tile's edge
     // lanes from the previous / next tile's centre (rotated into place), which is prefetched one
-    // tile ahead.
-    f32x4 prv[3][NB], cur[3][NB], nxt[3][NB];
+    // tile ahead (loads two tiles ahead).
+    f32x4 prv[3][NB], cur[3][NB], nxt[3][NB], nn[3][NB];
     auto load_rows = [&](int tile, f32x4 (&dst)[3][NB]) {
         const int xo = tile * 16 + i;
 #pragma unroll
@@ -133,11 +133,16 @@ __global__ void __launch_bounds__(256) k_gconv3x3(GConvArgs a)
 #pragma unroll
             for (int ci = 0; ci < NB; ++ci) prv[r][ci].x = prv[r][ci].y = prv[r][ci].z = prv[r][ci].w = 0.0f;
         load_rows(0, cur);
+        if (NB == 1) load_rows(1, nxt);
     }
     for (int tile = 0; tile < tiles; ++tile) {
         f32x4 v[9][NB];
         if (STRIDE == 1) {
-            load_rows(tile + 1, nxt);                  // zeros beyond the last tile
+            // the right edge lane of THIS tile needs the next tile's centre, so the loads run two
+            // tiles ahead: what is requested here is first used in the next iteration
+            // (the 32-channel variant has no registers to spare and stays one tile ahead)
+            if (NB == 1) load_rows(tile + 2, nn);      // zeros beyond the last tile
+            else load_rows(tile + 1, nxt);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -195,7 +200,10 @@ __global__ void __launch_bounds__(256) k_gconv3x3(GConvArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int ci = 0; ci < NB; ++ci) { prv[r][ci] = cur[r][ci]; cur[r][ci] = nxt[r][ci]; }
+                for (int ci = 0; ci < NB; ++ci) {
+                    prv[r][ci] = cur[r][ci]; cur[r][ci] = nxt[r][ci];
+                    if (NB == 1) nxt[r][ci] = nn[r][ci];
+                }
         }
     }
 }
