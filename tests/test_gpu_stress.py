@@ -170,11 +170,10 @@ def test_two_streams_give_the_single_stream_result():
     from iouaware.fuse import fuse_inference
     from test_host_model import R50_MODEL, TEST_CFG
     torch.manual_seed(1)
-    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).cuda().eval()
-    with torch.no_grad():
-        for p in m.bbox_head.parameters():
-            if p.dim() == 4:
-                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
+    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).eval()
+    with torch.no_grad():                  # wide score gaps: tests/synth.py, the E2E fixtures' scheme
+        synth.e2e_fill_state(m.state_dict(), 9)
+    m = m.cuda()
     fuse_inference(m, winograd=True)
     m = m.to(memory_format=torch.channels_last)
     xs = [torch.randn(2, 3, 192, 256, device='cuda').contiguous(memory_format=torch.channels_last)
@@ -198,8 +197,8 @@ def test_two_streams_give_the_single_stream_result():
                 # MIOpen may pick other algorithms on a new stream (its handle is per stream): the
                 # logits then differ in the last bits and near-ties in the top-100 may swap
                 assert torch.equal(r[3], o[3])
-                assert float((r[1] == o[1]).float().mean()) > 0.9
-                assert float(((r[0] - o[0]).abs().amax(-1) < 1e-3).float().mean()) > 0.9
+                assert float((r[1] == o[1]).float().mean()) >= 0.98
+                assert float(((r[0] - o[0]).abs().amax(-1) < 1e-3).float().mean()) >= 0.98
 
 
 @pytest.mark.parametrize('per_cluster', [10, 60, 200])

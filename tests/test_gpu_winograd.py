@@ -46,13 +46,12 @@ def test_head_matches_module_forward_and_detections():
     from test_host_model import R50_MODEL, TEST_CFG
     import synth
     torch.manual_seed(3)
-    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).cuda().eval()
-    # trained-like weights: the default init (std 0.01) would make every logit nearly constant
+    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).eval()
+    # trained-like weights with wide score gaps (tests/synth.py, the E2E fixtures' scheme): the
+    # default init (std 0.01) would make every logit nearly constant and every comparison a tie
     with torch.no_grad():
-        for p in m.bbox_head.parameters():
-            if p.dim() == 4:
-                p.normal_(0, (2.0 / (9 * p.shape[1])) ** 0.5)
-        m.bbox_head.retina_cls.bias.fill_(-4.0)
+        synth.e2e_fill_state(m.state_dict(), 5)
+    m = m.cuda()
     m = m.to(memory_format=torch.channels_last)
     img = _cl(torch.randn(2, 3, 224, 288, device='cuda'))
     metas = [synth.img_meta(220, 280, 224, 288) for _ in range(2)]
@@ -71,9 +70,10 @@ def test_head_matches_module_forward_and_detections():
         unfuse_inference(m)
         assert not hasattr(m.bbox_head, '_ia_wino')
         dets0 = m.simple_test_batch(img, metas, rescale=True)
-    for d, d0 in zip(dets, dets0):          # per-class lists: same number of detections (a score on
-        n, n0 = sum(len(x) for x in d), sum(len(x) for x in d0)      # the threshold may flip one)
-        assert n > 0 and abs(n - n0) <= 2
+    from test_gpu_e2e import _match_sets
+    for d, d0 in zip(dets, dets0):          # the same detections, class by class, within 1e-4
+        matched, total, _, _ = _match_sets(d0, d)
+        assert total > 0 and sum(len(x) for x in d) == total and matched >= total - 1, (matched, total)
 
 
 def test_whole_network_winograd_matches_module_path():
