@@ -79,7 +79,7 @@ def _gather_buffer(world, rec):
     return buf
 
 
-def all_gather_detections(dets, labels, num, num_samples=None):
+def all_gather_detections(dets, labels, num, num_samples=None, force_collective=False):
     """Gather every rank's per-image detections on every rank, in dataset order.
 
     Each rank passes its local batch (same B on every rank).  Returns
@@ -88,11 +88,12 @@ def all_gather_detections(dets, labels, num, num_samples=None):
     pre-allocated (W, B, M*6+1) buffer (RCCL on GPUs: a single ring / direct all-gather of
     W x B x 2.4 KB; gloo on CPU), falling back to the list form where a backend lacks it.
     The rank interleave copies out of that buffer, so the result stays valid.
+    force_collective: issue the collective even in a one-rank group (tests: RCCL on one GPU).
     """
     rank, world = get_dist_info()
     M = dets.shape[1]
     rec = pack_detections(dets, labels, num).contiguous()
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         allrec = rec
     else:
         buf = _gather_buffer(world, rec)
