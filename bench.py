@@ -230,7 +230,8 @@ TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_t
 TRAIN_BATCH = 4                           # imgs_per_gpu of the reference's 4-GPU config (:78)
 
 
-def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels_last=False):
+def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels_last=False,
+                 fuse=True):
     """BASELINE config 5, one GPU: whole training iterations of R-50 IoU-aware RetinaNet at
     800x1344, batch 4, fp32 -- forward, device target assignment + all-levels loss kernels,
     backward, gradient clipping, SGD (reference mmdet/apis/train.py:38-45, optimizer_config of
@@ -247,6 +248,12 @@ def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels
     opt = build_optimizer(model, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001))
     g = torch.Generator(device=device).manual_seed(7)
     img = torch.randn(TRAIN_BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
+    if fuse:
+        # bottlenecks / FPN: one autograd node per convolution on the GEMM / Winograd kernels,
+        # eval-mode BatchNorm folded differentiably; frozen stem + stage 1 on the inference kernels
+        from iouaware.fuse import fuse_inference
+        fuse_inference(model, winograd=True, train=True)
+        channels_last = True
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
         img = img.contiguous(memory_format=torch.channels_last)

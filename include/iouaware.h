@@ -235,6 +235,30 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
 int ia_wino_grad_output_transform(const ia_wino_geom *g, const float *const *dy, int channels,
                                   float *dM, void *stream);
 
+/* Training: the per-iteration weight transforms of the Winograd convolution nodes
+ * (iouaware/winograd_train.py) and the fused ReLU-backward / bias-gradient pass of the
+ * convolution nodes (iouaware/train_fuse.py); they stand where the reference's training step
+ * runs torch's convolution / BatchNorm / ReLU backward (mmdet/models/backbones/resnet.py:215-255,
+ * mmdet/models/anchor_heads/iou_aware_retina_head.py:171-219 under autograd).
+ *   ia_wino_weight_transform: U (36, n_in, n_out), U[6a+b][i][o] = (G w(o,i) G^T)[a][b]; w is
+ *     addressed by element strides (any memory format; swap stride_in / stride_out and set
+ *     flip=1 for the input-gradient convolution = correlation with w^T rotated by 180 degrees).
+ *     G: the 6x3 kernel-transform matrix of F(4x4,3x3), row-major doubles (host memory).
+ *   ia_wino_weight_grad: dW (n_out, n_in, 3, 3) contiguous = G^T dU(.,i,o) G, the adjoint.
+ *   ia_relu_bwd_bias_grad: dy, y, g (rows, n) row-major fp32 (n % 4 == 0, 16-byte aligned):
+ *     g = dy where y > 0 else 0 (y == NULL: no mask, nothing written), db[n] = column sums of
+ *     the masked gradient (db == NULL: not computed).  The sums go through per-strip partial
+ *     rows in the workspace and are added in a fixed order (same bits every run).            */
+#define IA_COLSUM_MAX_STRIPS 512
+size_t ia_relu_bwd_bias_grad_workspace_bytes(int64_t rows, int n);
+int ia_wino_weight_transform(const float *w, int n_in, int n_out, int64_t stride_in,
+                             int64_t stride_out, int64_t stride_ky, int64_t stride_kx, int flip,
+                             const double *G, float *U, void *stream);
+int ia_wino_weight_grad(const float *dU, int n_in, int n_out, const double *G, float *dW,
+                        void *stream);
+int ia_relu_bwd_bias_grad(const float *dy, const float *y, int64_t rows, int n, float *g, float *db,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* 1x1 convolution on a channels-last activation as one library GEMM (hipBLASLt) with the folded
  * BatchNorm bias, the residual and the ReLU in its epilogue (Bottleneck.forward,
  * mmdet/models/backbones/resnet.py:215-255, at inference):

@@ -98,6 +98,11 @@ SIGNATURES = {
     'ia_wino_input_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _i, _vp, _vp, _i,
                                      _vp, _vp]),
     'ia_wino_grad_output_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _vp, _vp]),
+    'ia_wino_weight_transform': (_i, [_vp, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i,
+                                      C.POINTER(C.c_double), _vp, _vp]),
+    'ia_wino_weight_grad': (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp, _vp]),
+    'ia_relu_bwd_bias_grad_workspace_bytes': (C.c_size_t, [C.c_int64, _i]),
+    'ia_relu_bwd_bias_grad': (_i, [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp, C.c_size_t, _vp]),
     'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
                                       C.POINTER(WinoSeg), _vp]),
     'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),

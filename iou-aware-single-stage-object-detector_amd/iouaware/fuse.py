@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
-from . import ops
+from . import ops, train_fuse
 from .backbones import BasicBlock, Bottleneck, ResNet
 from .layers import ConvModule
 
@@ -59,8 +59,11 @@ def _stamp(module):
 
 
 def _fast(module, x):
-    ok = (not module.training) and (not torch.is_grad_enabled()) and x.is_cuda \
-        and x.dtype in (torch.float32, torch.bfloat16)
+    # no autograd graph to build: grad mode off, or a frozen module (frozen_stages) fed an input
+    # that carries no gradient -- then the raw kernels' outputs (requires_grad False) are what
+    # eager would have produced as well
+    ok = (not module.training) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) \
+        and (not torch.is_grad_enabled() or train_fuse.frozen(module, x))
     if ok and module._ia_stamp != _stamp(module):
         _fold(module)              # parameters changed since the fold: derive the copies again
     return ok
@@ -70,8 +73,14 @@ def _conv_nobias(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def _train(module):
+    return len(module._ia_opts) > 2 and module._ia_opts[2]
+
+
 def _bottleneck_forward(self, x):
     if not _fast(self, x):
+        if _train(self) and train_fuse.bottleneck_usable(self, x):
+            return train_fuse.bottleneck_forward(self, x)      # training, eval-mode BatchNorm
         return type(self).forward(self, x)
     f = self._ia_fused
     lt = 'w1' in f and x.dtype in (torch.float32, torch.bfloat16) \
@@ -145,7 +154,22 @@ def _basic_forward(self, x):
 
 def _resnet_forward(self, x):
     if not _fast(self, x):
+        if _train(self) and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 \
+                and not x.requires_grad and not self.norm1.training \
+                and not any(p.requires_grad for m in (self.conv1, self.norm1)
+                            for p in m.parameters()):
+            # training with a frozen stem (frozen_stages >= 0): the stem on the inference kernels,
+            # the stages decide for themselves (frozen -> inference route, else train_fuse)
+            if self._ia_stamp != _stamp(self):
+                _fold(self)
+            with torch.no_grad():
+                x = self._stem(x.contiguous(memory_format=torch.channels_last))
+            return self._stages(x)
         return type(self).forward(self, x)
+    return self._stages(self._stem(x))
+
+
+def _resnet_stem(self, x):
     f = self._ia_fused
     x = self.conv1(x)
     mp = self.maxpool
@@ -154,6 +178,10 @@ def _resnet_forward(self, x):
         x = ops.affine_relu_maxpool(x, f['s'], f['b'])          # BN + ReLU + 3x3/2 max-pool, one pass
     else:
         x = mp(ops.channel_affine_act_(x, f['s'], f['b'], relu=True))
+    return x
+
+
+def _resnet_stages(self, x):
     outs = []
     for i, name in enumerate(self.res_layers):
         x = getattr(self, name)(x)
@@ -193,6 +221,8 @@ def _fpn_forward(self, inputs):
             and t.is_contiguous(memory_format=torch.channels_last)
             for t in inputs[self.start_level:self.backbone_end_level])
     if not ok:
+        if _train(self) and train_fuse.fpn_usable(self, inputs):
+            return train_fuse.fpn_forward(self, inputs)
         return type(self).forward(self, inputs)
     lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
     n = len(lat)
@@ -245,7 +275,7 @@ def _gemm_ok(conv):
 def _fold(m):
     """(re)derive the folded / transformed weight copies of one fused module from its current
     parameters.  Returns False for modules this file does not fuse."""
-    winograd, fpn_conv = m._ia_opts
+    winograd, fpn_conv = m._ia_opts[:2]
     if type(m).__name__ == 'FPN':
         return True                               # nothing folded: only the forward is replaced
     if type(m).__name__ == 'IoUawareRetinaHead':
@@ -343,8 +373,13 @@ def _forward_for(m, winograd):
     return None
 
 
-def fuse_inference(model, winograd=False):
+def fuse_inference(model, winograd=False, train=False):
     """Patch `model` in place (see module docstring).  Returns the number of fused modules.
+
+    train=True (with winograd=True) additionally gives the bottlenecks and the FPN a TRAINING
+    route (train_fuse.py): with grad mode on and eval-mode BatchNorm (`norm_eval=True`), every
+    convolution of a block is one autograd node on the GEMM / Winograd kernels; frozen stages
+    take the inference route.
 
     winograd=True additionally routes the head's 3x3 convolutions through the Winograd
     F(4x4,3x3) path (iouaware/winograd.py) whenever its inputs are channels-last fp32 CUDA
@@ -366,13 +401,16 @@ def fuse_inference(model, winograd=False):
         fwd = _forward_for(m, winograd)
         if fwd is None:
             continue
-        m._ia_opts = (bool(winograd), id(m) in fpn_convs)
+        m._ia_opts = (bool(winograd), id(m) in fpn_convs, bool(train and winograd))
         if not _fold(m):
             del m._ia_opts
             continue
         if type(m).__name__ == 'FPN':
             m._ia_stamp = ()
         m.forward = types.MethodType(fwd, m)
+        if isinstance(m, ResNet):
+            m._stem = types.MethodType(_resnet_stem, m)
+            m._stages = types.MethodType(_resnet_stages, m)
         n += 1
     return n
 
@@ -392,5 +430,6 @@ def unfuse_inference(model):
         for attr in ('_ia_fused', '_ia_wino', '_ia_opts', '_ia_stamp'):
             if hasattr(m, attr):
                 delattr(m, attr)
-                if 'forward' in m.__dict__:
-                    del m.__dict__['forward']
+                for name in ('forward', '_stem', '_stages'):
+                    if name in m.__dict__:
+                        del m.__dict__[name]

@@ -1,0 +1,230 @@
+"""Training forward / backward of the ResNet bottlenecks and the FPN on the library's own
+convolution paths (BASELINE config 5: the R-50 training iteration; reference resnet.py:215-255
+for the block, fpn.py:100-136 for the neck).
+
+In the reference's training configuration the backbone's BatchNorm layers run in eval mode
+(`norm_eval=True`: frozen statistics, trainable gamma / beta), so conv + BN is an affine map
+of the convolution output whose scale folds into the weight:
+
+    y = relu( conv(x, w * s) + b  [+ identity] ),    s = gamma / sqrt(var + eps),  b = beta - mean * s
+
+PyTorch eager runs that as MIOpen convolution (NCHW Winograd F(2x2) kernels fed through layout
+transposes) + BatchNorm + add + ReLU forward, and their four backward kernels, every one a full
+pass over the activation.  Here every convolution of a block is ONE autograd node over the
+channels-last activation:
+
+    1x1            `Conv1x1`: hipBLASLt GEMM with bias / identity / ReLU in the epilogue
+                   (ops.linear_bias_act, the inference kernel); backward = ReLU mask, then
+                   dx = g . w^T (the same GEMM entry point), dw = x^T . g split along the
+                   pixel dimension (a (C_in x C_out) result alone would occupy a handful of
+                   compute units), db = column sums
+    3x3, stride 1  winograd_train.wino_conv_levels: F(4x4,3x3) forward, input gradient and
+                   Winograd-domain weight gradient
+    3x3, stride 2  (three per network) torch's convolution on the folded weight
+
+The fold `w * s`, `beta - mean * s` is written in torch operations on the parameters, so autograd
+carries d(w*s), db back to w, gamma and beta; nothing of BatchNorm's own backward is left.
+Blocks whose parameters are all frozen (`frozen_stages`) and whose input carries no gradient take
+the inference route of fuse.py.  Everything here needs the HIP library; there is no fallback
+inside -- `usable()` decides before anything runs, and a module that does not qualify runs its
+ordinary forward.
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import ops
+from . import winograd_train as WT
+
+
+# ------------------------------------------------------------------ 1x1 convolution node
+def _split_for(P, k, n):
+    """how many slices of the pixel dimension the weight-gradient GEMM is cut into: enough
+    (k x n) result tiles to cover the 256 compute units a few times, slices >= 512 pixels"""
+    tiles = max(1, (k // 128 or 1) * (n // 128 or 1))
+    want = max(1, min(1024 // tiles, P // 512))
+    s = 1
+    for d in range(want, 0, -1):
+        if P % d == 0:
+            s = d
+            break
+    return s
+
+
+def weight_grad_1x1(x2, g2):
+    """x2 (P, k), g2 (P, n) -> x2^T g2 (k, n), the reduction over P cut into slices"""
+    P, k = x2.shape
+    n = g2.shape[1]
+    s = _split_for(P, k, n)
+    if s == 1:
+        return x2.t().mm(g2)
+    part = torch.bmm(x2.view(s, P // s, k).transpose(1, 2), g2.view(s, P // s, n))
+    return part.sum(0)
+
+
+def _rows(t):
+    """channels-last (B, C, H, W) -> (B*H*W, C) view"""
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _cl(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) \
+        else t.contiguous(memory_format=torch.channels_last)
+
+
+class Conv1x1(torch.autograd.Function):
+    """relu?( x . w_kn + bias + identity ) on channels-last fp32 activations"""
+
+    @staticmethod
+    def forward(ctx, x, w_kn, bias, identity, relu):
+        x = _cl(x)
+        w = w_kn.contiguous()
+        y = ops.linear_bias_act(x, w, None if bias is None else bias.contiguous(),
+                                residual=None if identity is None else _cl(identity), relu=relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        need_x, need_w, need_b, need_i = ctx.needs_input_grad[:4]
+        g, db = WT.relu_bwd_bias_grad(dy, y if ctx.relu else None, need_b)
+        dx = dw = None
+        if need_x:
+            dx = ops.linear_bias_act(g, w.t().contiguous(), None)
+        if need_w:
+            dw = weight_grad_1x1(_rows(x), _rows(g))
+        return dx, dw, db, (g if need_i else None), None
+
+
+def conv1x1(x, w_kn, bias=None, identity=None, relu=False):
+    return Conv1x1.apply(x, w_kn, bias, identity, relu)
+
+
+# ------------------------------------------------------------------ eval-mode BatchNorm fold
+def bn_affine(bn):
+    """eval-mode BatchNorm as (scale, shift), differentiable w.r.t. gamma / beta"""
+    key = (bn.running_var.data_ptr(), bn.running_var._version)
+    inv = getattr(bn, '_ia_inv', None)
+    if inv is None or inv[0] != key:
+        with torch.no_grad():
+            inv = bn._ia_inv = (key, torch.rsqrt(bn.running_var.float() + bn.eps))
+    inv = inv[1]
+    s = inv if bn.weight is None else bn.weight * inv
+    if bn.bias is None:
+        return s, -(bn.running_mean * s)
+    return s, torch.addcmul(bn.bias, bn.running_mean, s, value=-1.0)
+
+
+def _kn(conv, s):
+    """(Cout, Cin, 1, 1) weight * s[Cout] -> (Cin, Cout)"""
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    return (w * s.view(-1, 1)).t()
+
+
+def _gemm_ok(conv, stride_ok=(1,)):
+    return (tuple(conv.kernel_size) == (1, 1) and conv.stride[0] == conv.stride[1]
+            and conv.stride[0] in stride_ok and tuple(conv.padding) == (0, 0)
+            and conv.groups == 1 and conv.bias is None)
+
+
+def _eval_bn(m):
+    return isinstance(m, _BatchNorm) and not m.training and m.running_var is not None
+
+
+def _act_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+
+
+def frozen(module, x):
+    return (not x.requires_grad) and not any(p.requires_grad for p in module.parameters())
+
+
+def bottleneck_usable(m, x):
+    c2 = m.conv2
+    return (torch.is_grad_enabled() and _act_ok(x) and not m.with_cp
+            and _eval_bn(m.norm1) and _eval_bn(m.norm2) and _eval_bn(m.norm3)
+            and _gemm_ok(m.conv1) and _gemm_ok(m.conv3)
+            and tuple(c2.kernel_size) == (3, 3) and tuple(c2.padding) == (1, 1)
+            and tuple(c2.dilation) == (1, 1) and c2.groups == 1 and c2.bias is None
+            and c2.stride[0] == c2.stride[1] and c2.stride[0] in (1, 2)
+            and c2.in_channels % 4 == 0 and c2.out_channels % 4 == 0
+            and (m.downsample is None or (_gemm_ok(m.downsample[0], (1, 2))
+                                          and _eval_bn(m.downsample[1]))))
+
+
+def bottleneck_forward(m, x):
+    """Bottleneck.forward (reference resnet.py:215-255) in training, eval-mode BatchNorm"""
+    x = _cl(x)
+    s1, b1 = bn_affine(m.norm1)
+    s2, b2 = bn_affine(m.norm2)
+    s3, b3 = bn_affine(m.norm3)
+    out = conv1x1(x, _kn(m.conv1, s1), b1, None, True)
+    w2 = m.conv2.weight * s2.view(-1, 1, 1, 1)
+    if m.conv2.stride[0] == 1:
+        out = WT.wino_conv_levels([out], w2, b2, relu=True)[0]
+    else:
+        out = F.relu(F.conv2d(out, w2, b2, m.conv2.stride, m.conv2.padding))
+    if m.downsample is None:
+        idn = x
+    else:
+        ds, dn = m.downsample[0], m.downsample[1]
+        sd, bd = bn_affine(dn)
+        xs = x if ds.stride[0] == 1 else x[:, :, ::ds.stride[0], ::ds.stride[1]]
+        idn = conv1x1(xs, _kn(ds, sd), bd, None, False)
+    return conv1x1(out, _kn(m.conv3, s3), b3, idn, True)
+
+
+# ------------------------------------------------------------------ FPN
+def fpn_usable(m, inputs):
+    if not (torch.is_grad_enabled() and len(inputs) == len(m.in_channels)
+            and m.out_channels % 4 == 0):
+        return False
+    used = inputs[m.start_level:m.backbone_end_level]
+    if not all(_act_ok(t) and t.shape[1] % 4 == 0 for t in used):
+        return False
+    for lc in m.lateral_convs:
+        c = lc.conv
+        if lc.with_norm or lc.with_activatation or tuple(c.kernel_size) != (1, 1) \
+                or tuple(c.stride) != (1, 1) or tuple(c.padding) != (0, 0) or c.groups != 1:
+            return False
+    for fc in list(m.fpn_convs)[:len(m.lateral_convs)]:
+        c = fc.conv
+        if fc.with_norm or fc.with_activatation or tuple(c.kernel_size) != (3, 3) \
+                or tuple(c.stride) != (1, 1) or tuple(c.padding) != (1, 1) or c.groups != 1:
+            return False
+    return True
+
+
+def fpn_forward(m, inputs):
+    """FPN.forward (reference fpn.py:100-136): laterals as GEMMs with the upsampled coarser level
+    as the epilogue's identity operand, output convolutions on the Winograd path"""
+    n = len(m.lateral_convs)
+    lat = [None] * n
+    for i in range(n - 1, -1, -1):
+        c = m.lateral_convs[i].conv
+        x = _cl(inputs[i + m.start_level])
+        idn = None
+        if i < n - 1:
+            idn = F.interpolate(lat[i + 1], scale_factor=2, mode='nearest')
+            if tuple(idn.shape[-2:]) != tuple(x.shape[-2:]):
+                raise RuntimeError('FPN levels are not a factor of two apart')   # as the reference
+        w = c.weight.view(c.out_channels, c.in_channels).t()
+        lat[i] = conv1x1(x, w, c.bias, idn, False)
+    outs = []
+    for i in range(n):
+        c = m.fpn_convs[i].conv
+        outs.append(WT.wino_conv_levels([lat[i]], c.weight, c.bias, relu=False)[0])
+    if m.num_outs > n:
+        if not m.add_extra_convs:
+            for _ in range(m.num_outs - n):
+                outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        else:
+            first = inputs[m.backbone_end_level - 1] if m.extra_convs_on_inputs else outs[-1]
+            outs.append(m.fpn_convs[n](first))
+            for i in range(n + 1, m.num_outs):
+                src = F.relu(outs[-1]) if m.relu_before_extra_convs else outs[-1]
+                outs.append(m.fpn_convs[i](src))
+    return tuple(outs)

@@ -171,7 +171,10 @@ class WinogradConv3x3(object):
         self._plans = {}
 
     def usable(self, x):
-        return _usable(x) and x.shape[1] == self.cin and not torch.is_grad_enabled()
+        # raw kernels, no autograd graph: grad mode off, or an input that carries no gradient
+        # (a frozen stage during training; fuse._fast has checked the parameters)
+        return _usable(x) and x.shape[1] == self.cin \
+            and not (torch.is_grad_enabled() and x.requires_grad)
 
     def __call__(self, x, pre=None):
         """pre = (scale, shift, relu): x is the raw output of the convolution in front, its folded

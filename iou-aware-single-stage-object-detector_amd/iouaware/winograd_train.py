@@ -25,6 +25,8 @@ multiplications per 4x4 output tile instead of MIOpen's 64, and all levels in on
 Activations are channels-last fp32; the transformed weights are recomputed from the parameters
 in every call (they change every iteration).
 """
+import ctypes
+
 import torch
 
 from . import winograd as W
@@ -72,14 +74,64 @@ def grad_output_transform(plan, dys, out):
     return out
 
 
+_G_HOST = (ctypes.c_double * 18)(*[float(v) for v in W._G.reshape(-1)])
+
+
+def transform_weight(w, adjoint=False):
+    """(Cout, Cin, 3, 3) fp32 CUDA weight (any strides) -> U (36, Cin, Cout), U[6a+b] = (G w G^T)[a,b]
+    (csrc/trainops.hip, once per iteration and convolution).  adjoint=True: the weight of the
+    input-gradient convolution, w^T rotated by 180 degrees -> (36, Cout, Cin)."""
+    from . import _lib
+    from .ops import _ptr, _stream
+    if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
+        raise TypeError('transform_weight needs a (Cout, Cin, 3, 3) fp32 CUDA weight')
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    so, si, sy, sx = w.stride()
+    n_in, n_out, s_in, s_out = (cout, cin, so, si) if adjoint else (cin, cout, si, so)
+    u = torch.empty((36, n_in, n_out), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.lib().ia_wino_weight_transform(_ptr(w), n_in, n_out, s_in, s_out, sy, sx,
+                                                   int(bool(adjoint)), _G_HOST, _ptr(u), _stream()),
+               'ia_wino_weight_transform')
+    return u
+
+
 def untransform_weight_grad(du):
     """(36, Cin, Cout) gradient w.r.t. U = G g G^T  ->  (Cout, Cin, 3, 3) gradient w.r.t. g"""
-    G = W._G_DEV.get(du.device)
-    if G is None:
-        G = W._G_DEV[du.device] = torch.from_numpy(W._G).to(du.device)
-    cin, cout = du.shape[1], du.shape[2]
-    d6 = du.reshape(6, 6, cin, cout).to(torch.float64)
-    return torch.einsum('ik,ijco,jl->ockl', G, d6, G).to(torch.float32)
+    from . import _lib
+    from .ops import _ptr, _stream
+    du = du.contiguous()
+    cin, cout = int(du.shape[1]), int(du.shape[2])
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=du.device)
+    _lib.check(_lib.lib().ia_wino_weight_grad(_ptr(du), cin, cout, _G_HOST, _ptr(dw), _stream()),
+               'ia_wino_weight_grad')
+    return dw
+
+
+def relu_bwd_bias_grad(dy, y=None, bias_grad=True):
+    """channels-last (B, C, H, W) fp32: (dy masked by y > 0 [dy itself when y is None],
+    per-channel sums of the masked gradient [None unless bias_grad]) in one pass"""
+    from . import _lib
+    from .ops import _ptr, _stream
+    dy = _cl(dy)
+    B, Cn, H, Wd = dy.shape
+    if y is None and not bias_grad:
+        return dy, None
+    if Cn % 4:
+        g = dy if y is None else torch.ops.aten.threshold_backward(dy, y, 0)
+        return g, (g.sum((0, 2, 3)) if bias_grad else None)
+    g = dy if y is None else torch.empty_like(dy)
+    db = ws = None
+    nbytes = 0
+    if bias_grad:
+        from .ops import _workspace
+        db = torch.empty(Cn, dtype=torch.float32, device=dy.device)
+        nbytes = int(_lib.lib().ia_relu_bwd_bias_grad_workspace_bytes(B * H * Wd, Cn))
+        ws = _workspace(dy.device, nbytes)
+    _lib.check(_lib.lib().ia_relu_bwd_bias_grad(_ptr(dy), None if y is None else _ptr(_cl(y)),
+                                                B * H * Wd, Cn, None if y is None else _ptr(g),
+                                                _ptr(db), _ptr(ws), nbytes, _stream()),
+               'ia_relu_bwd_bias_grad')
+    return g, db
 
 
 class _WinoConvLevels(torch.autograd.Function):
@@ -91,9 +143,9 @@ class _WinoConvLevels(torch.autograd.Function):
         plan = _plan(xs)
         cout = weight.shape[0]
         with torch.no_grad():
-            u = W.transform_weight(weight)                                   # (36, Cin, Cout)
+            u = transform_weight(weight)                                     # (36, Cin, Cout)
             b = None if bias is None else bias.detach().float().contiguous()
-            keep = weight.requires_grad
+            keep = ctx.needs_input_grad[0]
             out = _conv_levels(plan, xs, u, b, relu, cout, 'f', keep_v=keep)
             ys, v = out if keep else (out, None)
         ctx.relu, ctx.has_bias, ctx.plan, ctx.L = bool(relu), bias is not None, plan, len(xs)
@@ -111,23 +163,27 @@ class _WinoConvLevels(torch.autograd.Function):
         v = saved[-1] if (len(saved) > 1 + (L if ctx.relu else 0)) else None
         plan = ctx.plan
         with torch.no_grad():
-            dys = [_cl(d) for d in dys]
-            if ys is not None:                      # ReLU backward: dy where y > 0
-                dys = [torch.ops.aten.threshold_backward(d, y, 0) for d, y in zip(dys, ys)]
+            want_b = ctx.has_bias and ctx.needs_input_grad[1]
+            db = None
+            masked = []
+            for l, d in enumerate(dys):              # ReLU backward (dy where y > 0) + bias sums
+                g, b = relu_bwd_bias_grad(d, ys[l] if ys is not None else None, want_b)
+                masked.append(g)
+                if want_b:
+                    db = b if db is None else db + b
+            dys = masked
             need_x = any(ctx.needs_input_grad[3 + l] for l in range(L))
             dxs = [None] * L
             if need_x:
                 # adjoint of correlation with w (pad 1) = correlation with w^T flipped (pad 1)
-                ut = W.transform_weight(weight.flip(2, 3).transpose(0, 1))    # (36, Cout, Cin)
+                ut = transform_weight(weight, adjoint=True)                   # (36, Cout, Cin)
                 dxs = _conv_levels(plan, dys, ut, None, False, weight.shape[1], 'b')
-            dw = db = None
+            dw = None
             if ctx.needs_input_grad[0] and v is not None:
                 cout = weight.shape[0]
                 dm = grad_output_transform(plan, dys, plan.buf('tdm', (36, plan.T, cout)))
                 du = torch.bmm(v.transpose(1, 2), dm)                         # (36, Cin, Cout)
                 dw = untransform_weight_grad(du)
-            if ctx.has_bias and ctx.needs_input_grad[1]:
-                db = sum(d.sum((0, 2, 3)) for d in dys)
         return (dw, db, None) + tuple(dxs)
 
 

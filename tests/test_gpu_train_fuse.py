@@ -1,0 +1,168 @@
+"""GPU: the training route of the bottlenecks / FPN (iouaware/train_fuse.py: GEMM and Winograd
+autograd nodes, eval-mode BatchNorm folded differentiably) against the plain nn.Module forward
+(MIOpen + BatchNorm + autograd): outputs, input gradients and every parameter gradient."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _rel2(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize('k,n,bias,idn,relu', [(256, 64, True, False, True), (64, 256, True, True, True),
+                                               (512, 128, False, False, False),
+                                               (2048, 256, True, True, False)])
+def test_conv1x1_node_vs_conv2d_autograd(k, n, bias, idn, relu):
+    from iouaware.train_fuse import conv1x1
+    g = torch.Generator(device='cuda').manual_seed(k + n)
+    w = torch.randn(n, k, 1, 1, device='cuda', generator=g) * (1.0 / k) ** 0.5
+    b = torch.randn(n, device='cuda', generator=g) * 0.1 if bias else None
+    x0 = torch.randn(3, k, 23, 40, device='cuda', generator=g)
+    i0 = torch.randn(3, n, 23, 40, device='cuda', generator=g) if idn else None
+    up = torch.randn(3, n, 23, 40, device='cuda', generator=g)
+    res = {}
+    for mode in ('node', 'ref'):
+        wp = w.clone().requires_grad_(True)
+        bp = b.clone().requires_grad_(True) if bias else None
+        x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ip = i0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True) if idn else None
+        if mode == 'node':
+            y = conv1x1(x, wp.view(n, k).t(), bp, ip, relu)
+        else:
+            y = F.conv2d(x, wp, bp)
+            y = y + ip if idn else y
+            y = F.relu(y) if relu else y
+        (y * up).sum().backward()
+        res[mode] = [y.detach(), x.grad, wp.grad] + ([bp.grad] if bias else []) + ([ip.grad] if idn else [])
+    for a, c in zip(res['node'], res['ref']):
+        assert a.shape == c.shape and _rel(a, c) < 1e-4, (_rel(a, c))
+
+
+def test_weight_grad_split_matches_plain_product():
+    from iouaware.train_fuse import weight_grad_1x1, _split_for
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for P, k, n in ((4 * 100 * 168, 128, 512), (4 * 25 * 42, 2048, 512), (1000, 64, 64), (977, 256, 64)):
+        x = torch.randn(P, k, device='cuda', generator=g)
+        d = torch.randn(P, n, device='cuda', generator=g)
+        ref = (x.double().t() @ d.double()).float()
+        assert P % _split_for(P, k, n) == 0
+        assert _rel(weight_grad_1x1(x, d), ref) < 1e-5
+
+
+def _block(inplanes, planes, stride, down):
+    import torch.nn as nn
+    from iouaware.backbones import Bottleneck
+    from iouaware.layers import build_norm_layer
+    ds = None
+    if down:
+        ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                           build_norm_layer(dict(type='BN'), planes * 4)[1])
+    m = Bottleneck(inplanes, planes, stride, downsample=ds).cuda()
+    pre = 'backbone.layer2.0.'               # the fill rules are keyed on the detector's names
+    state = {pre + k: v for k, v in m.state_dict().items()}
+    synth.e2e_fill_state(state, 11)
+    m.load_state_dict({k[len(pre):]: v for k, v in state.items()})
+    with torch.no_grad():                    # non-trivial affine parameters everywhere
+        for name, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    m.train()
+    for b in m.modules():
+        if isinstance(b, nn.modules.batchnorm._BatchNorm):
+            b.eval()                          # norm_eval=True
+    return m
+
+
+@pytest.mark.parametrize('inplanes,planes,stride,down', [(256, 64, 1, False), (256, 128, 2, True),
+                                                         (64, 64, 1, True)])
+def test_bottleneck_training_route_vs_module(inplanes, planes, stride, down):
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    m = _block(inplanes, planes, stride, down)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x0 = torch.randn(2, inplanes, 44, 60, device='cuda', generator=g).relu()
+    up = None
+    res = {}
+    for mode in ('ref', 'fused'):
+        if mode == 'fused':
+            assert fuse_inference(m, winograd=True, train=True) > 0
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = m(x)
+        if up is None:
+            up = torch.randn(y.shape, device='cuda', generator=g)
+        (y * up).sum().backward()
+        res[mode] = (y.detach(), x.grad, {k: p.grad.clone() for k, p in m.named_parameters()})
+    unfuse_inference(m)
+    (ya, xa, pa), (yb, xb, pb) = res['fused'], res['ref']
+    assert ya.shape == yb.shape and _rel(ya, yb) < 1e-4
+    # ReLU masks may differ where a pre-activation is within rounding of zero: norm-wise
+    assert _rel2(xa, xb) < 1e-3
+    assert set(pa) == set(pb)
+    for k in pb:
+        assert _rel2(pa[k], pb[k]) < 1e-3, (k, _rel2(pa[k], pb[k]))
+
+
+def test_frozen_block_takes_the_inference_route_under_grad_mode():
+    from iouaware.fuse import fuse_inference
+    m = _block(256, 64, 1, False)
+    m.eval()
+    for p in m.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 256, 20, 28, device='cuda').contiguous(memory_format=torch.channels_last)
+    ref = m(x)
+    fuse_inference(m, winograd=True, train=True)
+    y = m(x)
+    assert not y.requires_grad and _rel(y, ref) < 1e-4
+
+
+def test_whole_detector_training_iteration_fused_vs_module():
+    """R-50 IoU-aware RetinaNet (frozen_stages=1, norm_eval=True), trained-like weights, one
+    iteration at 2 x 256 x 320: losses and all parameter gradients, fused training route vs
+    plain modules"""
+    import iouaware
+    import bench
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    from iouaware.train import parse_losses
+    gts, gls = synth.train_targets(11, 2, 250, 317, max_gt=6)
+    gtb = [torch.from_numpy(x).cuda() for x in gts]
+    gtl = [torch.from_numpy(x).cuda() for x in gls]
+    metas = [synth.img_meta(250, 317, 256, 320) for _ in range(2)]
+    img = torch.from_numpy(synth.e2e_image(3, 2, 256, 320, 250, 317)).cuda()
+    res = {}
+    for mode in ('ref', 'fused'):
+        torch.manual_seed(0)
+        model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=ConfigDict(bench.TRAIN_CFG),
+                                        test_cfg=ConfigDict(bench.TEST_CFG))
+        state = model.state_dict()
+        synth.e2e_fill_state(state, 7)
+        model.load_state_dict(state)
+        model = model.cuda().train()
+        x = img
+        if mode == 'fused':
+            model.bbox_head.train_winograd = True
+            assert fuse_inference(model, winograd=True, train=True) > 0
+            x = img.contiguous(memory_format=torch.channels_last)
+        else:
+            model.bbox_head.train_winograd = False
+        losses = model(x, metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+        loss, logv = parse_losses(losses)
+        loss.backward()
+        res[mode] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters()
+                                   if p.grad is not None})
+    (la, ga), (lb, gb) = res['fused'], res['ref']
+    assert abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
+    assert set(ga) == set(gb)
+    worst = max((_rel2(ga[k], gb[k]), k) for k in gb)
+    assert worst[0] < 2e-2, worst
+    total = torch.cat([g.flatten() for g in ga.values()]), torch.cat([gb[k].flatten() for k in ga])
+    assert _rel2(*total) < 2e-3

@@ -141,3 +141,43 @@ def test_training_iteration_same_losses_and_grads():
     assert set(ga) == set(gb)
     for n in gb:
         assert _rel2(ga[n], gb[n]) < 1e-2, (n, _rel2(ga[n], gb[n]))
+
+
+@pytest.mark.parametrize('cout,cin,cl', [(256, 256, False), (128, 64, True), (48, 256, False), (512, 512, True)])
+def test_weight_transform_kernels_vs_float64_einsum(cout, cin, cl):
+    """csrc/trainops.hip: U = G w G^T, its flipped / transposed variant for the input gradient,
+    and the adjoint G^T dU G, against float64 einsums rounded once"""
+    from iouaware import winograd as W
+    from iouaware import winograd_train as WT
+    g = torch.Generator(device='cuda').manual_seed(cout + cin)
+    w = torch.randn(cout, cin, 3, 3, device='cuda', generator=g)
+    if cl:
+        w = w.contiguous(memory_format=torch.channels_last)
+    def close(a, b):                  # both round a float64 result once; the sums differ in order
+        return a.shape == b.shape and float((a - b).abs().max()) <= 2e-7 * float(b.abs().max())
+    assert close(WT.transform_weight(w), W.transform_weight(w))
+    assert close(WT.transform_weight(w, adjoint=True),
+                 W.transform_weight(w.flip(2, 3).transpose(0, 1)))
+    du = torch.randn(36, cin, cout, device='cuda', generator=g)
+    G = torch.from_numpy(W._G).cuda()
+    ref = torch.einsum('ik,ijco,jl->ockl', G, du.reshape(6, 6, cin, cout).double(), G)
+    got = WT.untransform_weight_grad(du)
+    assert got.shape == (cout, cin, 3, 3)
+    assert float((got.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 33, 47), (3, 720, 13, 21), (2, 2048, 8, 11), (1, 36, 5, 7),
+                                   (4, 256, 100, 168), (2, 1280, 9, 9)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_relu_backward_and_bias_gradient_one_pass(shape, relu):
+    from iouaware import winograd_train as WT
+    g = torch.Generator(device='cuda').manual_seed(shape[1])
+    dy = torch.randn(shape, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    y = torch.randn(shape, device='cuda', generator=g).relu().contiguous(memory_format=torch.channels_last)
+    got, db = WT.relu_bwd_bias_grad(dy, y if relu else None, True)
+    ref = dy * (y > 0) if relu else dy
+    assert torch.equal(got, ref)
+    rs = ref.double().sum((0, 2, 3))
+    assert float((db.double() - rs).abs().max()) <= 1e-5 * float(ref.abs().double().sum((0, 2, 3)).max())
+    got2, none = WT.relu_bwd_bias_grad(dy, y if relu else None, False)
+    assert none is None and torch.equal(got2, ref)

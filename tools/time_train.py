@@ -8,13 +8,17 @@ import torch, bench, synth, iouaware
 from iouaware.config import ConfigDict
 from iouaware.train import build_optimizer, train_step
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-torch.backends.cudnn.benchmark = True
+torch.backends.cudnn.benchmark = not os.environ.get('NOFIND')
 TRAIN_CFG = ConfigDict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
                                      ignore_iof_thr=-1), allowed_border=-1, pos_weight=-1, debug=False)
 torch.manual_seed(0)
 model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=TRAIN_CFG, test_cfg=ConfigDict(bench.TEST_CFG)).cuda().train()
 opt = build_optimizer(model, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001))
 img = torch.randn(B, 3, 800, 1344, device='cuda')
+if os.environ.get('FUSE'):
+    from iouaware.fuse import fuse_inference
+    print('fused modules', fuse_inference(model, winograd=True, train=True))
+    os.environ['CL'] = '1'
 if os.environ.get('CL'):
     model = model.to(memory_format=torch.channels_last); img = img.contiguous(memory_format=torch.channels_last)
 gts, gls = synth.train_targets(5, B, 800, 1333, max_gt=20)

@@ -2,5 +2,5 @@ import sys, os, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch, bench
 t = time.time()
-r = bench.train_record(torch.device('cuda', 0), find=bool(int(sys.argv[1])), loss_part=not os.environ.get('TRAIN_ONLY'), channels_last=bool(os.environ.get('CL')))
+r = bench.train_record(torch.device('cuda', 0), find=bool(int(sys.argv[1])), loss_part=not os.environ.get('TRAIN_ONLY'), channels_last=bool(os.environ.get('CL')), fuse=not os.environ.get('NOFUSE'))
 print('benchmark', sys.argv[1], 'total %.1f s' % (time.time() - t), r['value'], 'img/s', r['ms_per_iter'], 'ms/iter loss part', r['loss_part_ms'])
