@@ -398,6 +398,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl')
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
+    from iouaware import ops
+    ops.gemm_tuning('all')          # library GEMMs: time every supporting kernel per shape (+2 %)
 
     model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw,
                         winograd=not args.no_winograd)

@@ -244,7 +244,13 @@ int ia_wino_grad_output_transform(const ia_wino_geom *g, const float *const *dy,
  *     addressed by element strides (any memory format; swap stride_in / stride_out and set
  *     flip=1 for the input-gradient convolution = correlation with w^T rotated by 180 degrees).
  *     G: the 6x3 kernel-transform matrix of F(4x4,3x3), row-major doubles (host memory).
- *   ia_wino_weight_grad: dW (n_out, n_in, 3, 3) contiguous = G^T dU(.,i,o) G, the adjoint.
+ *   ia_wino_weight_grad: dW (n_out, n_in, 3, 3), addressed by element strides like w above
+ *     = G^T dU(.,i,o) G, the adjoint.
+ *   ia_bn_fold_fwd / _bwd: eval-mode BatchNorm (`norm_eval=True`, resnet.py:520-527) folded into the
+ *     convolution in front of it, differentiably: w_out[o][:] = w[o][:] * s, b_out = beta - mean * s,
+ *     s = gamma * inv_std (inv_std = 1/sqrt(running_var + eps), a constant); backward gives dw,
+ *     dgamma, dbeta from the gradients w.r.t. w_out / b_out.  Weights are (cout, K) rows, dense in
+ *     memory (contiguous or channels-last alike; all four weight-shaped arrays share one layout).
  *   ia_relu_bwd_bias_grad: dy, y, g (rows, n) row-major fp32 (n % 4 == 0, 16-byte aligned):
  *     g = dy where y > 0 else 0 (y == NULL: no mask, nothing written), db[n] = column sums of
  *     the masked gradient (db == NULL: not computed).  The sums go through per-strip partial
@@ -255,7 +261,13 @@ int ia_wino_weight_transform(const float *w, int n_in, int n_out, int64_t stride
                              int64_t stride_out, int64_t stride_ky, int64_t stride_kx, int flip,
                              const double *G, float *U, void *stream);
 int ia_wino_weight_grad(const float *dU, int n_in, int n_out, const double *G, float *dW,
+                        int64_t stride_in, int64_t stride_out, int64_t stride_ky, int64_t stride_kx,
                         void *stream);
+int ia_bn_fold_fwd(const float *w, const float *gamma, const float *beta, const float *mean,
+                   const float *inv_std, int cout, int K, float *w_out, float *b_out, void *stream);
+int ia_bn_fold_bwd(const float *dw_folded, const float *db_folded, const float *w, const float *gamma,
+                   const float *mean, const float *inv_std, int cout, int K, float *dw,
+                   float *dgamma, float *dbeta, void *stream);
 int ia_relu_bwd_bias_grad(const float *dy, const float *y, int64_t rows, int n, float *g, float *db,
                           void *workspace, size_t workspace_bytes, void *stream);
 
@@ -277,6 +289,26 @@ int ia_linear_bias_act_bf16(const void *A, const void *W, const float *bias, con
  * b < batch, contiguous row-major stacks; same library, same per-shape candidate timing.      */
 int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows, int k, int n,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* How many candidates the first call of a GEMM shape times: 0 = the library heuristic's top 16
+ * (default; or 1 when the environment has IA_GEMM_TUNE=all at the first GEMM), 1 = every kernel of
+ * the library that supports the problem (~250 for fp32, ~0.3 s per shape; +2 % img/s on the R-50
+ * inference step).  Shapes already chosen keep their choice.  Returns the previous mode; any other
+ * argument only queries.                                                                        */
+int ia_gemm_tuning(int mode);
+
+/* Training forms of the same library GEMM (convolution autograd nodes, iouaware/train_fuse.py):
+ *   ia_linear_bias_act_wt: as ia_linear_bias_act with the weight stored (n, k) row-major -- the
+ *     (Cout, Cin) convolution weight as it is, read through the library's transpose flag;
+ *   ia_gemm_tn: D[b] (n, k) = G[b]^T (n, rows) . X[b] (rows, k), b < batch: the weight gradient of
+ *     a 1x1 convolution (G = output gradient, X = input) and, batch = 36, of the Winograd-domain
+ *     product; a reduction over `rows` with a small result, the timed candidates include the
+ *     library's split-K kernels (give it a workspace).                                          */
+int ia_linear_bias_act_wt(const float *A, const float *W_nk, const float *bias,
+                          const float *residual, float *D, int64_t rows, int k, int n, int relu,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int ia_gemm_tn(const float *G, const float *X, float *D, int batch, int64_t rows, int n, int k,
+               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------- training
  * Per-level losses of IoUawareRetinaHead.loss_single (:221-313), computed on

@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void k_wino_weight(WinoWeightArgs a)
 }
 
 struct WinoWeightGradArgs {
-    const float *du; float *dw;        // du (36, n_in, n_out); dw (n_out, n_in, 3, 3) contiguous
+    const float *du; float *dw;        // du (36, n_in, n_out); dw (n_out, n_in, 3, 3), any strides
     int n_in, n_out;
+    long s_in, s_out, s_ky, s_kx;
     double G[6][3];
 };
 
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void k_wino_weight_grad(WinoWeightGradArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r) t[r][c] += a.G[k][r] * v;
         }
-    float *q = a.dw + ((long)o * a.n_in + i) * 9;
+    float *q = a.dw + (long)o * a.s_out + (long)i * a.s_in;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_wino_weight_grad(WinoWeightGradArgs a)
             double v = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) v += t[r][k] * a.G[k][c];
-            q[r * 3 + c] = (float)v;
+            q[r * a.s_ky + c * a.s_kx] = (float)v;
         }
 }
 
@@ -185,6 +186,55 @@ __global__ __launch_bounds__(256) void k_colsum_finish(ReluColsumArgs a)
     }
 }
 
+// Eval-mode BatchNorm folded into the convolution in front of it, per output channel o (one
+// workgroup each, K = Cin*kh*kw weights that are dense in memory whatever the memory format):
+//   forward    s = gamma * inv_std,  w'[o][:] = w[o][:] * s,  b'[o] = beta - mean * s
+//   backward   dw[o][:] = dw'[o][:] * s,  dgamma = inv_std * (sum_j dw'[o][j] w[o][j] - mean * db'),
+//              dbeta = db'
+// (eager: 3 small kernels forward and ~8 backward per convolution, 42 convolutions per iteration)
+struct FoldArgs {
+    const float *w, *gamma, *beta, *mean, *inv;
+    const float *dwp, *dbp;            // backward: gradients w.r.t. w', b' (dbp may be NULL = 0)
+    float *w_out, *b_out;              // forward outputs
+    float *dw, *dgamma, *dbeta;        // backward outputs (dw may be NULL: frozen weight)
+    int K;
+};
+
+__global__ __launch_bounds__(256) void k_bn_fold_fwd(FoldArgs a)
+{
+    const int o = blockIdx.x;
+    const float s = a.gamma[o] * a.inv[o];
+    const float *w = a.w + (long)o * a.K;
+    float *q = a.w_out + (long)o * a.K;
+    for (int j = threadIdx.x; j < a.K; j += 256) q[j] = w[j] * s;
+    if (threadIdx.x == 0) a.b_out[o] = a.beta[o] - a.mean[o] * s;
+}
+
+__global__ __launch_bounds__(256) void k_bn_fold_bwd(FoldArgs a)
+{
+    __shared__ float red[4];
+    const int o = blockIdx.x;
+    const float s = a.gamma[o] * a.inv[o];
+    const float *w = a.w + (long)o * a.K, *g = a.dwp + (long)o * a.K;
+    float *q = a.dw ? a.dw + (long)o * a.K : nullptr;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < a.K; j += 256) {
+        const float gv = g[j];
+        acc += gv * w[j];
+        if (q) q[j] = gv * s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float dot = (red[0] + red[1]) + (red[2] + red[3]);
+        const float db = a.dbp ? a.dbp[o] : 0.f;
+        a.dgamma[o] = a.inv[o] * (dot - a.mean[o] * db);
+        a.dbeta[o] = db;
+    }
+}
+
 }  // namespace ia
 
 extern "C" {
@@ -207,11 +257,13 @@ int ia_wino_weight_transform(const float *w, int n_in, int n_out, int64_t stride
 }
 
 int ia_wino_weight_grad(const float *dU, int n_in, int n_out, const double *G, float *dW,
+                        int64_t stride_in, int64_t stride_out, int64_t stride_ky, int64_t stride_kx,
                         void *stream)
 {
     if (!dU || !dW || !G || n_in < 1 || n_out < 1) return IA_E_ARG;
     ia::WinoWeightGradArgs a;
     a.du = dU; a.dw = dW; a.n_in = n_in; a.n_out = n_out;
+    a.s_in = stride_in; a.s_out = stride_out; a.s_ky = stride_ky; a.s_kx = stride_kx;
     for (int r = 0; r < 6; ++r)
         for (int c = 0; c < 3; ++c) a.G[r][c] = G[r * 3 + c];
     const long total = (long)n_in * n_out;
@@ -257,3 +309,29 @@ int ia_relu_bwd_bias_grad(const float *dy, const float *y, int64_t rows, int n, 
 }
 
 }  // extern "C"
+
+extern "C" int ia_bn_fold_fwd(const float *w, const float *gamma, const float *beta, const float *mean,
+                              const float *inv_std, int cout, int K, float *w_out, float *b_out,
+                              void *stream)
+{
+    if (!w || !gamma || !beta || !mean || !inv_std || !w_out || !b_out || cout < 1 || K < 1)
+        return IA_E_ARG;
+    ia::FoldArgs a = {};
+    a.w = w; a.gamma = gamma; a.beta = beta; a.mean = mean; a.inv = inv_std;
+    a.w_out = w_out; a.b_out = b_out; a.K = K;
+    hipLaunchKernelGGL(ia::k_bn_fold_fwd, dim3((unsigned)cout), dim3(256), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
+
+extern "C" int ia_bn_fold_bwd(const float *dw_folded, const float *db_folded, const float *w,
+                              const float *gamma, const float *mean, const float *inv_std, int cout,
+                              int K, float *dw, float *dgamma, float *dbeta, void *stream)
+{
+    if (!dw_folded || !w || !gamma || !mean || !inv_std || !dgamma || !dbeta || cout < 1 || K < 1)
+        return IA_E_ARG;
+    ia::FoldArgs a = {};
+    a.w = w; a.gamma = gamma; a.mean = mean; a.inv = inv_std; a.dwp = dw_folded; a.dbp = db_folded;
+    a.dw = dw; a.dgamma = dgamma; a.dbeta = dbeta; a.K = K;
+    hipLaunchKernelGGL(ia::k_bn_fold_bwd, dim3((unsigned)cout), dim3(256), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}

@@ -100,7 +100,10 @@ SIGNATURES = {
     'ia_wino_grad_output_transform': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_void_p), _i, _vp, _vp]),
     'ia_wino_weight_transform': (_i, [_vp, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i,
                                       C.POINTER(C.c_double), _vp, _vp]),
-    'ia_wino_weight_grad': (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp, _vp]),
+    'ia_wino_weight_grad': (_i, [_vp, _i, _i, C.POINTER(C.c_double), _vp, C.c_int64, C.c_int64,
+                                 C.c_int64, C.c_int64, _vp]),
+    'ia_bn_fold_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'ia_bn_fold_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     'ia_relu_bwd_bias_grad_workspace_bytes': (C.c_size_t, [C.c_int64, _i]),
     'ia_relu_bwd_bias_grad': (_i, [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp, C.c_size_t, _vp]),
     'ia_wino_output_transform': (_i, [C.POINTER(WinoGeom), _vp, _i, _i, _vp, _i, _i,
@@ -108,6 +111,9 @@ SIGNATURES = {
     'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_linear_bias_act_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_batched_gemm': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    'ia_linear_bias_act_wt': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    'ia_gemm_tuning': (_i, [_i]),
+    'ia_gemm_tn': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     'ia_smooth_l1_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

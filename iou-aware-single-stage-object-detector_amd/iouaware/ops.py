@@ -456,17 +456,21 @@ def affine_relu_maxpool(x, scale, shift):
 _LT_WS_BYTES = 64 << 20
 
 
-def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False):
+def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
     """1x1 convolution of a channels-last (B, k, H, W) fp32 tensor as one hipBLASLt GEMM:
-    relu?(x . w_kn + bias + residual) -> channels-last (B, n, H, W).  w_kn: (k, n) row-major."""
+    relu?(x . w_kn + bias + residual) -> channels-last (B, n, H, W).  w_kn: (k, n) row-major;
+    w_nk=True: the weight is given as (n, k) row-major instead (a (Cout, Cin) convolution weight
+    as it is; fp32 only -- the training route)."""
     _require_gpu(x, 'x')
     B, k, H, W = x.shape
-    n = int(w_kn.shape[1])
+    n = int(w_kn.shape[0 if w_nk else 1])
     if x.dtype not in (torch.float32, torch.bfloat16) or \
             not x.is_contiguous(memory_format=torch.channels_last):
         raise TypeError('linear_bias_act needs a channels-last fp32 / bf16 activation')
-    if tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous() or w_kn.dtype != x.dtype:
-        raise ValueError('weight must be a contiguous (k, n) matrix of the activation dtype')
+    if tuple(w_kn.shape) != ((n, k) if w_nk else (k, n)) or not w_kn.is_contiguous() \
+            or w_kn.dtype != x.dtype:
+        raise ValueError('weight must be a contiguous (k, n) [w_nk: (n, k)] matrix of the '
+                         'activation dtype')
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError('bias must be fp32')
     out = torch.empty((B, n, H, W), dtype=x.dtype, device=x.device,
@@ -478,14 +482,43 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False):
         raise TypeError('residual dtype mismatch')
     ws = _workspace(x.device, _LT_WS_BYTES)
     if x.dtype == torch.bfloat16:
+        if w_nk:
+            raise TypeError('w_nk is fp32 only')
         _lib.check(_lib.lib().ia_linear_bias_act_bf16(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual),
                                                       _ptr(out), B * H * W, k, n, int(bool(relu)),
                                                       _ptr(ws), _LT_WS_BYTES, _stream()),
                    'ia_linear_bias_act_bf16')
         return out
-    _lib.check(_lib.lib().ia_linear_bias_act(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual),
-                                             _ptr(out), B * H * W, k, n, int(bool(relu)), _ptr(ws),
-                                             _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')
+    fn = _lib.lib().ia_linear_bias_act_wt if w_nk else _lib.lib().ia_linear_bias_act
+    _lib.check(fn(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out), B * H * W, k, n,
+                  int(bool(relu)), _ptr(ws), _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')
+    return out
+
+
+def gemm_tuning(mode=None):
+    """'all': the first call of every new GEMM shape times every library kernel that supports it
+    (~0.3 s per shape); 'heuristic': the library heuristic's top 16 (default).  Returns the mode
+    in force before the call; None only queries."""
+    code = {'heuristic': 0, 'all': 1, None: -1}[mode]
+    return ('heuristic', 'all')[_lib.lib().ia_gemm_tuning(code)]
+
+
+def gemm_tn(g, x):
+    """g (rows, n) or (batch, rows, n), x (rows, k) or (batch, rows, k), fp32 contiguous ->
+    g^T x: (n, k) / (batch, n, k).  The weight-gradient product of the convolution nodes: a
+    reduction over `rows` with a small result (library GEMM, split-K candidates timed)."""
+    _require_gpu(g, 'g')
+    if g.dtype != torch.float32 or x.dtype != torch.float32 or g.dim() != x.dim() \
+            or g.dim() not in (2, 3) or g.shape[:-1] != x.shape[:-1] \
+            or not g.is_contiguous() or not x.is_contiguous():
+        raise ValueError('gemm_tn needs contiguous fp32 (.., rows, n) and (.., rows, k)')
+    batch = int(g.shape[0]) if g.dim() == 3 else 1
+    rows, n, k = int(g.shape[-2]), int(g.shape[-1]), int(x.shape[-1])
+    out = torch.empty(((batch, n, k) if g.dim() == 3 else (n, k)), dtype=torch.float32,
+                      device=g.device)
+    ws = _workspace(g.device, _LT_WS_BYTES)
+    _lib.check(_lib.lib().ia_gemm_tn(_ptr(g), _ptr(x), _ptr(out), batch, rows, n, k, _ptr(ws),
+                                     _LT_WS_BYTES, _stream()), 'ia_gemm_tn')
     return out
 
 

@@ -14,16 +14,18 @@ pass over the activation.  Here every convolution of a block is ONE autograd nod
 channels-last activation:
 
     1x1            `Conv1x1`: hipBLASLt GEMM with bias / identity / ReLU in the epilogue
-                   (ops.linear_bias_act, the inference kernel); backward = ReLU mask, then
-                   dx = g . w^T (the same GEMM entry point), dw = x^T . g split along the
-                   pixel dimension (a (C_in x C_out) result alone would occupy a handful of
-                   compute units), db = column sums
+                   (ops.linear_bias_act, the inference kernel, the (Cout, Cin) weight read
+                   through the transpose flag); backward = ReLU mask + bias gradient in one
+                   pass (csrc/trainops.hip), dx = g . w (the same GEMM entry point),
+                   dw = g^T . x cut into slices of the pixel dimension (a (Cout x Cin) result
+                   alone would occupy a handful of compute units)
     3x3, stride 1  winograd_train.wino_conv_levels: F(4x4,3x3) forward, input gradient and
                    Winograd-domain weight gradient
     3x3, stride 2  (three per network) torch's convolution on the folded weight
 
-The fold `w * s`, `beta - mean * s` is written in torch operations on the parameters, so autograd
-carries d(w*s), db back to w, gamma and beta; nothing of BatchNorm's own backward is left.
+The fold `w * s`, `beta - mean * s` is one more autograd node on the parameters (`FoldBN`, one
+kernel forward, one backward), which carries d(w*s), db back to w, gamma and beta; nothing of
+BatchNorm's own backward is left.
 Blocks whose parameters are all frozen (`frozen_stages`) and whose input carries no gradient take
 the inference route of fuse.py.  Everything here needs the HIP library; there is no fallback
 inside -- `usable()` decides before anything runs, and a module that does not qualify runs its
@@ -73,15 +75,22 @@ def _cl(t):
         else t.contiguous(memory_format=torch.channels_last)
 
 
+# 'bmm': weight_grad_1x1, the reduction over the pixels cut into slices (batched GEMM + sum);
+# 'lt': ops.gemm_tn, one library GEMM (its timed candidates do not split the reduction well:
+# 38.7 vs 36.9 ms per R-50 iteration)
+WGRAD = 'bmm'
+
+
 class Conv1x1(torch.autograd.Function):
-    """relu?( x . w_kn + bias + identity ) on channels-last fp32 activations"""
+    """relu?( x . w^T + bias + identity ) on channels-last fp32 activations; w: (Cout, Cin)"""
 
     @staticmethod
-    def forward(ctx, x, w_kn, bias, identity, relu):
+    def forward(ctx, x, w_nk, bias, identity, relu):
         x = _cl(x)
-        w = w_kn.contiguous()
+        w = w_nk.contiguous()
         y = ops.linear_bias_act(x, w, None if bias is None else bias.contiguous(),
-                                residual=None if identity is None else _cl(identity), relu=relu)
+                                residual=None if identity is None else _cl(identity), relu=relu,
+                                w_nk=True)
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -93,35 +102,93 @@ class Conv1x1(torch.autograd.Function):
         g, db = WT.relu_bwd_bias_grad(dy, y if ctx.relu else None, need_b)
         dx = dw = None
         if need_x:
-            dx = ops.linear_bias_act(g, w.t().contiguous(), None)
+            dx = ops.linear_bias_act(g, w, None)          # (rows, Cout) . (Cout, Cin)
         if need_w:
-            dw = weight_grad_1x1(_rows(x), _rows(g))
+            g2, x2 = _rows(g), _rows(x)
+            dw = ops.gemm_tn(g2, x2) if WGRAD == 'lt' else weight_grad_1x1(g2, x2)
         return dx, dw, db, (g if need_i else None), None
 
 
-def conv1x1(x, w_kn, bias=None, identity=None, relu=False):
-    return Conv1x1.apply(x, w_kn, bias, identity, relu)
+def conv1x1(x, w_nk, bias=None, identity=None, relu=False):
+    return Conv1x1.apply(x, w_nk, bias, identity, relu)
 
 
 # ------------------------------------------------------------------ eval-mode BatchNorm fold
-def bn_affine(bn):
-    """eval-mode BatchNorm as (scale, shift), differentiable w.r.t. gamma / beta"""
+def _inv_std(bn):
     key = (bn.running_var.data_ptr(), bn.running_var._version)
     inv = getattr(bn, '_ia_inv', None)
     if inv is None or inv[0] != key:
         with torch.no_grad():
-            inv = bn._ia_inv = (key, torch.rsqrt(bn.running_var.float() + bn.eps))
-    inv = inv[1]
-    s = inv if bn.weight is None else bn.weight * inv
-    if bn.bias is None:
-        return s, -(bn.running_mean * s)
-    return s, torch.addcmul(bn.bias, bn.running_mean, s, value=-1.0)
+            inv = bn._ia_inv = (key, torch.rsqrt(bn.running_var.float() + bn.eps).contiguous())
+    return inv[1]
 
 
-def _kn(conv, s):
-    """(Cout, Cin, 1, 1) weight * s[Cout] -> (Cin, Cout)"""
-    w = conv.weight.view(conv.out_channels, conv.in_channels)
-    return (w * s.view(-1, 1)).t()
+def _dense_rows(w):
+    """every output channel's Cin*kh*kw weights dense in memory (contiguous / channels-last)"""
+    return w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))
+
+
+def _same_layout(a, b):
+    cl = torch.channels_last
+    return (a.is_contiguous() and b.is_contiguous()) or \
+        (a.dim() == 4 and a.is_contiguous(memory_format=cl) and b.is_contiguous(memory_format=cl))
+
+
+class FoldBN(torch.autograd.Function):
+    """(w, gamma, beta) -> (w * s, beta - mean * s), s = gamma / sqrt(var + eps): eval-mode
+    BatchNorm folded into the convolution in front of it; one kernel forward, one backward
+    (csrc/trainops.hip)"""
+
+    @staticmethod
+    def forward(ctx, w, gamma, beta, mean, inv):
+        from . import _lib
+        from .ops import _ptr, _stream
+        cout = int(w.shape[0])
+        wf = torch.empty_like(w)
+        bf = torch.empty(cout, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.lib().ia_bn_fold_fwd(_ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(inv),
+                                             cout, w.numel() // cout, _ptr(wf), _ptr(bf), _stream()),
+                   'ia_bn_fold_fwd')
+        ctx.save_for_backward(w, gamma, mean, inv)
+        return wf, bf
+
+    @staticmethod
+    def backward(ctx, dwf, dbf):
+        from . import _lib
+        from .ops import _ptr, _stream
+        w, gamma, mean, inv = ctx.saved_tensors
+        cout = int(w.shape[0])
+        if dwf is None:                                   # only the shift was used
+            dwf = torch.zeros_like(w)
+        elif not _same_layout(dwf, w):
+            dwf = torch.empty_like(w).copy_(dwf)
+        dw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        _lib.check(_lib.lib().ia_bn_fold_bwd(_ptr(dwf), _ptr(None if dbf is None else dbf.contiguous()),
+                                             _ptr(w), _ptr(gamma), _ptr(mean), _ptr(inv), cout,
+                                             w.numel() // cout, _ptr(dw), _ptr(dgamma), _ptr(dbeta),
+                                             _stream()), 'ia_bn_fold_bwd')
+        return dw, dgamma, dbeta, None, None
+
+
+def fold_bn(conv, bn):
+    """conv weight and eval-mode BatchNorm -> (folded weight, shift), differentiable w.r.t. the
+    weight, gamma and beta"""
+    w = conv.weight
+    inv = _inv_std(bn)
+    if bn.weight is not None and bn.bias is not None and w.is_cuda and w.dtype == torch.float32 \
+            and bn.weight.dtype == torch.float32 and _dense_rows(w):
+        return FoldBN.apply(w, bn.weight, bn.bias, bn.running_mean, inv)
+    s = inv if bn.weight is None else bn.weight * inv             # BatchNorm without affine part
+    shift = -(bn.running_mean * s) if bn.bias is None \
+        else torch.addcmul(bn.bias, bn.running_mean, s, value=-1.0)
+    return w * s.view(-1, 1, 1, 1), shift
+
+
+def _nk(w):
+    """(Cout, Cin, 1, 1) -> (Cout, Cin)"""
+    return w.view(w.shape[0], w.shape[1])
 
 
 def _gemm_ok(conv, stride_ok=(1,)):
@@ -158,11 +225,10 @@ def bottleneck_usable(m, x):
 def bottleneck_forward(m, x):
     """Bottleneck.forward (reference resnet.py:215-255) in training, eval-mode BatchNorm"""
     x = _cl(x)
-    s1, b1 = bn_affine(m.norm1)
-    s2, b2 = bn_affine(m.norm2)
-    s3, b3 = bn_affine(m.norm3)
-    out = conv1x1(x, _kn(m.conv1, s1), b1, None, True)
-    w2 = m.conv2.weight * s2.view(-1, 1, 1, 1)
+    w1, b1 = fold_bn(m.conv1, m.norm1)
+    w2, b2 = fold_bn(m.conv2, m.norm2)
+    w3, b3 = fold_bn(m.conv3, m.norm3)
+    out = conv1x1(x, _nk(w1), b1, None, True)
     if m.conv2.stride[0] == 1:
         out = WT.wino_conv_levels([out], w2, b2, relu=True)[0]
     else:
@@ -170,11 +236,11 @@ def bottleneck_forward(m, x):
     if m.downsample is None:
         idn = x
     else:
-        ds, dn = m.downsample[0], m.downsample[1]
-        sd, bd = bn_affine(dn)
+        ds = m.downsample[0]
+        wd, bd = fold_bn(ds, m.downsample[1])
         xs = x if ds.stride[0] == 1 else x[:, :, ::ds.stride[0], ::ds.stride[1]]
-        idn = conv1x1(xs, _kn(ds, sd), bd, None, False)
-    return conv1x1(out, _kn(m.conv3, s3), b3, idn, True)
+        idn = conv1x1(xs, _nk(wd), bd, None, False)
+    return conv1x1(out, _nk(w3), b3, idn, True)
 
 
 # ------------------------------------------------------------------ FPN
@@ -211,8 +277,7 @@ def fpn_forward(m, inputs):
             idn = F.interpolate(lat[i + 1], scale_factor=2, mode='nearest')
             if tuple(idn.shape[-2:]) != tuple(x.shape[-2:]):
                 raise RuntimeError('FPN levels are not a factor of two apart')   # as the reference
-        w = c.weight.view(c.out_channels, c.in_channels).t()
-        lat[i] = conv1x1(x, w, c.bias, idn, False)
+        lat[i] = conv1x1(x, c.weight.view(c.out_channels, c.in_channels), c.bias, idn, False)
     outs = []
     for i in range(n):
         c = m.fpn_convs[i].conv

@@ -95,15 +95,20 @@ def transform_weight(w, adjoint=False):
     return u
 
 
-def untransform_weight_grad(du):
-    """(36, Cin, Cout) gradient w.r.t. U = G g G^T  ->  (Cout, Cin, 3, 3) gradient w.r.t. g"""
+def untransform_weight_grad(du, like=None):
+    """(36, Cin, Cout) gradient w.r.t. U = G g G^T  ->  (Cout, Cin, 3, 3) gradient w.r.t. g, with the
+    strides of `like` (the weight: contiguous or channels-last) when given"""
     from . import _lib
     from .ops import _ptr, _stream
     du = du.contiguous()
     cin, cout = int(du.shape[1]), int(du.shape[2])
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=du.device)
-    _lib.check(_lib.lib().ia_wino_weight_grad(_ptr(du), cin, cout, _G_HOST, _ptr(dw), _stream()),
-               'ia_wino_weight_grad')
+    if like is not None and tuple(like.shape) == (cout, cin, 3, 3):
+        dw = torch.empty_like(like, dtype=torch.float32)
+    else:
+        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=du.device)
+    so, si, sy, sx = dw.stride()
+    _lib.check(_lib.lib().ia_wino_weight_grad(_ptr(du), cin, cout, _G_HOST, _ptr(dw), si, so, sy, sx,
+                                              _stream()), 'ia_wino_weight_grad')
     return dw
 
 
@@ -132,6 +137,9 @@ def relu_bwd_bias_grad(dy, y=None, bias_grad=True):
                                                 _ptr(db), _ptr(ws), nbytes, _stream()),
                'ia_relu_bwd_bias_grad')
     return g, db
+
+
+DU = 'lt'             # 'lt': ops.gemm_tn (library candidates timed per shape); 'bmm': torch.bmm
 
 
 class _WinoConvLevels(torch.autograd.Function):
@@ -182,8 +190,9 @@ class _WinoConvLevels(torch.autograd.Function):
             if ctx.needs_input_grad[0] and v is not None:
                 cout = weight.shape[0]
                 dm = grad_output_transform(plan, dys, plan.buf('tdm', (36, plan.T, cout)))
-                du = torch.bmm(v.transpose(1, 2), dm)                         # (36, Cin, Cout)
-                dw = untransform_weight_grad(du)
+                from .ops import gemm_tn
+                du = gemm_tn(v, dm) if DU == 'lt' else torch.bmm(v.transpose(1, 2), dm)   # (36, Cin, Cout)
+                dw = untransform_weight_grad(du, like=weight)
         return (dw, db, None) + tuple(dxs)
 
 

@@ -36,7 +36,7 @@ def test_conv1x1_node_vs_conv2d_autograd(k, n, bias, idn, relu):
         x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
         ip = i0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True) if idn else None
         if mode == 'node':
-            y = conv1x1(x, wp.view(n, k).t(), bp, ip, relu)
+            y = conv1x1(x, wp.view(n, k), bp, ip, relu)
         else:
             y = F.conv2d(x, wp, bp)
             y = y + ip if idn else y
@@ -56,6 +56,45 @@ def test_weight_grad_split_matches_plain_product():
         ref = (x.double().t() @ d.double()).float()
         assert P % _split_for(P, k, n) == 0
         assert _rel(weight_grad_1x1(x, d), ref) < 1e-5
+        from iouaware import ops
+        assert _rel(ops.gemm_tn(x, d), ref) < 1e-5                  # (k, n) = x^T d
+    xb = torch.randn(36, 1000, 64, device='cuda', generator=g)
+    db = torch.randn(36, 1000, 48, device='cuda', generator=g)
+    assert _rel(ops.gemm_tn(xb, db), torch.bmm(xb.transpose(1, 2).double(), db.double()).float()) < 1e-5
+
+
+@pytest.mark.parametrize('shape,cl', [((256, 64, 1, 1), False), ((128, 128, 3, 3), True),
+                                      ((512, 256, 3, 3), False), ((2048, 512, 1, 1), True)])
+def test_bn_fold_node_vs_torch_ops(shape, cl):
+    """FoldBN (one kernel each way) against the fold written in torch operations + autograd"""
+    import torch.nn as nn
+    from iouaware.train_fuse import fold_bn
+    g = torch.Generator(device='cuda').manual_seed(shape[0])
+    conv = nn.Conv2d(shape[1], shape[0], shape[2], bias=False).cuda()
+    bn = nn.BatchNorm2d(shape[0]).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(shape, device='cuda', generator=g))
+        bn.weight.copy_(torch.rand(shape[0], device='cuda', generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(shape[0], device='cuda', generator=g))
+        bn.running_mean.copy_(torch.randn(shape[0], device='cuda', generator=g))
+        bn.running_var.copy_(torch.rand(shape[0], device='cuda', generator=g) + 0.5)
+    if cl:
+        conv = conv.to(memory_format=torch.channels_last)
+    uw = torch.randn(shape, device='cuda', generator=g)
+    ub = torch.randn(shape[0], device='cuda', generator=g)
+    res = {}
+    for mode in ('node', 'ref'):
+        for p in (conv.weight, bn.weight, bn.bias):
+            p.grad = None
+        if mode == 'node':
+            wf, bf = fold_bn(conv, bn)
+        else:
+            s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            wf, bf = conv.weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
+        ((wf * uw).sum() + (bf * ub).sum()).backward()
+        res[mode] = (wf.detach(), bf.detach(), conv.weight.grad, bn.weight.grad, bn.bias.grad)
+    for a, c in zip(res['node'], res['ref']):
+        assert a.shape == c.shape and _rel(a, c) < 1e-5, _rel(a, c)
 
 
 def _block(inplanes, planes, stride, down):

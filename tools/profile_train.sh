@@ -8,6 +8,6 @@ rm -rf /tmp/pt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -- env TRAIN_ONLY=1 python $ROOT/tools/try_train_find.py ${FIND:-0} > /tmp/pt.log 2>&1
 tail -2 /tmp/pt.log
 mkdir -p $ROOT/gpurun_out/profile
-python $ROOT/tools/summarize_trace.py /tmp/pt/*/*_kernel_trace.csv --steps 4 --marker "k_assign<true>" --top 45 \
+python $ROOT/tools/summarize_trace.py /tmp/pt/*/*_kernel_trace.csv --steps 4 --marker "k_assign<true>" --top 60 \
     > $ROOT/gpurun_out/profile/train_step_summary.txt
-head -50 $ROOT/gpurun_out/profile/train_step_summary.txt | cut -c1-150
+(head -24; echo ...; tail -10) < $ROOT/gpurun_out/profile/train_step_summary.txt | cut -c1-150

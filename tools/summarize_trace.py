@@ -51,3 +51,25 @@ print('%-112s %8s %10s %10s %6s' % ('kernel', 'calls/st', 'avg us', 'ms/step', '
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
     print('%-112s %8.1f %10.1f %10.3f %6.2f' % (k, c / args.steps, t / c / 1e3, t / 1e6 / args.steps,
                                                  100.0 * t / 1e6 / args.steps / busy))
+
+# roll-up by kind: who owns the time
+KINDS = [('library GEMM (hipBLASLt / rocBLAS)', r'^Cijk_'),
+         ('MIOpen / CK convolution', r'igemm_|miopen|Sp3Asm|ck::|kernel_grouped_conv|batched_transpose|SubTensorOp|MIOpen'),
+         ('Winograd transforms (ia::k_wino_*)', r'ia::k_wino_'),
+         ('other kernels of this library (ia::)', r'ia::'),
+         ('torch copies / fills', r'direct_copy|fillBuffer|copyBuffer|FillFunctor'),
+         ('torch reductions', r'reduce_kernel'),
+         ('torch optimizer / clip (multi_tensor)', r'multi_tensor_apply'),
+         ('torch elementwise + rest', r'.')]
+kinds = collections.OrderedDict((k, [0, 0]) for k, _ in KINDS)
+for k, (c, t) in agg.items():
+    for name, pat in KINDS:
+        if re.search(pat, k):
+            kinds[name][0] += c
+            kinds[name][1] += t
+            break
+print()
+print('%-112s %8s %10s %10s %6s' % ('by kind', 'calls/st', '', 'ms/step', '%'))
+for name, (c, t) in kinds.items():
+    print('%-112s %8.1f %10s %10.3f %6.2f' % (name, c / args.steps, '', t / 1e6 / args.steps,
+                                               100.0 * t / 1e6 / args.steps / busy))
