@@ -188,9 +188,14 @@ def cpu_baseline(model, stepper):
     oracle.build()
     cpu_model = copy.deepcopy(model).to('cpu').eval()   # fused forwards fall back on CPU tensors
     img = stepper.imgs[:1].cpu()
-    threads = torch.get_num_threads()
+    threads0 = torch.get_num_threads()
+    # the cores this process may run on (a container's cpuset can be far smaller than the host)
+    threads = max(1, min(threads0, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(threads)
     with torch.no_grad():
-        cpu_model.forward_head(img[:, :, :64, :64])          # warm the allocator / oneDNN
+        # one untimed pass at full size: oneDNN creates its primitives / reorders the weights at
+        # the first call of every shape, which is not steady-state throughput
+        cpu_model.forward_head(img)
         t0 = time.time()
         cls, reg, iou = cpu_model.forward_head(img)
         t_conv = time.time() - t0
@@ -210,7 +215,7 @@ def cpu_baseline(model, stepper):
             cpu_model.forward_head(img)
             t_conv1 = time.time() - t0
     finally:
-        torch.set_num_threads(threads)
+        torch.set_num_threads(threads0)
     total = t_conv + t_post
     into_nms = int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum())
     name = cpu_model_name()
@@ -301,6 +306,7 @@ def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels
 
 
 PMC_PROFILE = 'r02_head_pmc.json'
+WINO_PMC_PROFILE = 'r02_wino_pmc.json'
 
 
 def wino_roofline(stepper, steps=2):
@@ -327,10 +333,22 @@ def wino_roofline(stepper, steps=2):
                              ms_per_step=round(sum(r[1] for r in sel) / steps, 3),
                              achieved=round(sum(r[2] for r in sel) / (sum(r[1] for r in sel) * 1e-3)
                                             / 1e9, 1))
+    traffic = None
+    try:                         # measured HBM bytes of the head-layer launches (tools/collect_wino_pmc.sh)
+        with open(os.path.join(ROOT, 'profiles', WINO_PMC_PROFILE)) as f:
+            prof = json.load(f)
+        traffic = dict(launch='head layer, batch 8, both towers (11440 tiles x 512 channels)',
+                       algorithmic_bytes=int(prof['algorithmic_bytes_per_launch']),
+                       k_wino_in=int(prof['kernels']['ia::k_wino_in']['traffic_bytes_per_launch']),
+                       k_wino_out=int(prof['kernels']['ia::k_wino_out']['traffic_bytes_per_launch']),
+                       source='profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                              'passes, 2 x FETCH_SIZE)' % WINO_PMC_PROFILE)
+    except Exception:
+        pass
     return dict(bound='hbm', kernel='k_wino_in + k_wino_out', achieved=round(achieved, 1),
                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                 launches_per_step=len(rec) // steps, ms_per_step=round(ms / steps, 3),
-                bytes_per_step=nbytes // steps, by_kernel=per,
+                bytes_per_step=nbytes // steps, by_kernel=per, traffic=traffic,
                 note='algorithmic bytes: input transform 16 + 36, output transform 36 + 16 fp32 '
                      'values per tile and channel; HIP events in %d steps after the timed region'
                      % steps)
