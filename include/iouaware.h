@@ -452,6 +452,28 @@ int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, i
                      const float *result, const float *grad_result, const ia_level_ptrs *grads,
                      void *stream);
 
+/* The same losses on CHANNELS-LAST fp32 head outputs (what the training head of
+ * iouaware/winograd_train.py produces): element (b, p, a, c) of a class map at
+ * (b*HW + p) * pix_stride + a*C + c -- the reference's flattened order
+ * cls_score.permute(0, 2, 3, 1).reshape(-1, C) (iou_aware_retina_head.py:236-240) in place, so the
+ * anchor-major targets index it directly (no packed copy; the workspace holds only the fp64 sums).
+ * pix_stride (elements) may exceed the map's own channel count: reg / iou may be channel slices
+ * of one wider tensor.  C % 4 == 0; cls / reg pointers and strides 16-byte aligned.  g->layout is
+ * not consulted.  Gradients are written with their own pixel strides (e.g. into the slices of one
+ * tensor shaped like the wider one).                                                        */
+typedef struct ia_level_pix_strides {
+    int64_t cls[IA_MAX_LEVELS], reg[IA_MAX_LEVELS], iou[IA_MAX_LEVELS];
+} ia_level_pix_strides;
+int ia_head_loss_fwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
+                          const ia_level_pix_strides *strides, int batch, const ia_head_targets *t,
+                          const ia_head_loss_cfg *cfg, void *workspace, size_t workspace_bytes,
+                          float *result, void *stream);
+int ia_head_loss_bwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
+                          const ia_level_pix_strides *strides, int batch, const ia_head_targets *t,
+                          const ia_head_loss_cfg *cfg, const float *result, const float *grad_result,
+                          const ia_level_ptrs *grads, const ia_level_pix_strides *grad_strides,
+                          void *stream);
+
 /* ------------------------------------------------------------------ ResNeXt grouped 3x3 convolution
  * conv2 of the ResNeXt bottleneck (mmdet/models/backbones/resnext.py:12-91: groups = 32 / 64,
  * 4 / 8 / 16 / 32 channels per group), channels-last fp32, pad 1, stride 1 or 2, + per-channel

@@ -431,6 +431,199 @@ __global__ void __launch_bounds__(256) k_box_ml(BoxMLArgs a)
     }
 }
 
+// ------------------------------------------------------------------ channels-last head outputs
+// The training head (winograd_train.py) produces channels-last tensors: element (b, p, a, c) of a
+// class map sits at (b*HW + p) * pix_stride + a*C + c, i.e. in the reference's flattened order
+// (cls_score.permute(0, 2, 3, 1).reshape(-1, C), iou_aware_retina_head.py:236-240) -- the targets
+// (anchor-major n = (b, p, a)) index it directly, no packed copy, and every load / store is a
+// 16-byte piece of a contiguous run.  reg / iou may be channel slices of one wider tensor
+// (pix_stride > A*4 / A).  fp32 only.
+struct NhwcLevels {
+    int32_t L, B, A, C;
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], stride[IA_MAX_LEVELS];
+    int32_t fblk_off[IA_MAX_LEVELS + 1];      // focal: blocks of kFocalChunks float4 chunks, launch order
+    int32_t bblk_off[IA_MAX_LEVELS + 1];      // box: blocks of 256 anchors, launch order
+};
+constexpr int kFocalU = 4;                    // float4 chunks per thread
+constexpr int kFocalChunks = 256 * kFocalU;   // per block
+
+struct FocalNhwcArgs {
+    NhwcLevels lv;
+    const float *cls[IA_MAX_LEVELS];
+    int64_t ps_cls[IA_MAX_LEVELS], ps_grad[IA_MAX_LEVELS];   // pixel strides (elements)
+    const int64_t *labels[IA_MAX_LEVELS];
+    const float *lw[IA_MAX_LEVELS];
+    float *grad[IA_MAX_LEVELS];
+    double *sums;
+    const float *gin, *res;
+    float alpha_pos, alpha_neg, loss_weight;
+    int32_t big_logits;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
+{
+    __shared__ double red[4];
+    int o = 0;
+    while ((int)blockIdx.x >= a.lv.fblk_off[o + 1]) ++o;
+    const int l = a.lv.L - 1 - o;
+    const int A = a.lv.A, C = a.lv.C, C4 = C >> 2, AC4 = A * C4;
+    const int64_t HW = (int64_t)a.lv.H[l] * a.lv.W[l];
+    const int64_t nchunks = (int64_t)a.lv.B * HW * AC4;
+    const int64_t base = (int64_t)(blockIdx.x - a.lv.fblk_off[o]) * kFocalChunks + threadIdx.x;
+    const float gs = BWD ? upstream(a.gin, a.res, a.lv.L, 0, l, a.loss_weight) : 1.0f;
+    const float *cls = a.cls[l];
+    const int64_t ps = a.ps_cls[l], pg = BWD ? a.ps_grad[l] : 0;
+    float4 v[kFocalU];
+    int64_t anchor[kFocalU];
+    int cq[kFocalU];
+    int64_t goff[kFocalU];
+    bool on[kFocalU];
+#pragma unroll
+    for (int u = 0; u < kFocalU; ++u) {
+        int64_t ch = base + 256 * u;
+        on[u] = ch < nchunks;
+        if (!on[u]) ch = nchunks - 1;                       // clamped: loads unconditional
+        const int64_t pix = ch / AC4;                       // (b, p)
+        const int r = (int)(ch - pix * AC4);                // a * C4 + class quad
+        anchor[u] = pix * A + r / C4;
+        cq[u] = r % C4;
+        typedef float F4 __attribute__((ext_vector_type(4)));
+        const F4 q = __builtin_nontemporal_load(reinterpret_cast<const F4 *>(cls + pix * ps + 4 * r));
+        v[u] = make_float4(q.x, q.y, q.z, q.w);
+        goff[u] = pix * pg + 4 * r;
+    }
+    double total = 0.0;
+#pragma unroll
+    for (int u = 0; u < kFocalU; ++u) {
+        const int lab = (int)a.labels[l][anchor[u]];
+        const float w0 = on[u] ? a.lw[l][anchor[u]] : 0.0f;
+        const float wn = (a.alpha_neg * w0) * gs, wp = (a.alpha_pos * w0) * gs;
+        const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        float t[4], rq[4], lg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(__builtin_fminf(x[k], kXMax) * kLog2e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sk = 1.0f + t[k];
+            rq[k] = __builtin_amdgcn_rcpf(sk);
+            lg[k] = __builtin_amdgcn_logf(sk);
+        }
+        const int jp = lab - 1 - 4 * cq[u];                 // the positive class's slot in this quad
+        float o4[4], acc = 0.0f, fix = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            Sig g; g.q = rq[k]; g.lg = lg[k]; g.p = t[k] * rq[k];
+            if (k == jp) {
+                if (BWD) o4[k] = pos_der(g, __builtin_fminf(x[k], kXMax)) * wp;
+                else fix = pos_val(g, __builtin_fminf(x[k], kXMax)) * wp;
+            } else {
+                if (BWD) o4[k] = neg_der(g) * wn;
+                else {
+                    acc += neg_val2(g);
+                    if (a.big_logits && x[k] > kXMax) fix += (x[k] - kXMax) * wn;   // exact tail
+                }
+            }
+        }
+        if (BWD) {
+            if (on[u]) *reinterpret_cast<float4 *>(a.grad[l] + goff[u]) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        } else total += (double)__builtin_fmaf(acc * kLn2, wn, fix);
+    }
+    if (!BWD) {
+        const double d = wave_sum(total);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicAdd(a.sums + (size_t)(0 * a.lv.L + l) * IA_LOSS_SLOTS + (blockIdx.x & kSlotMask),
+                      (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+struct BoxNhwcArgs {
+    NhwcLevels lv;
+    BaseAnchors ba;
+    const float *reg[IA_MAX_LEVELS], *iou[IA_MAX_LEVELS];
+    int64_t ps_reg[IA_MAX_LEVELS], ps_iou[IA_MAX_LEVELS], pg_reg[IA_MAX_LEVELS], pg_iou[IA_MAX_LEVELS];
+    const float *bt[IA_MAX_LEVELS], *bw[IA_MAX_LEVELS];
+    float *g_reg[IA_MAX_LEVELS], *g_iou[IA_MAX_LEVELS];
+    double *sums;
+    const float *gin, *res;
+    float means[4], stds[4];
+    float beta, lw_bbox, lw_iou;
+    int32_t attach;
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_box_nhwc(BoxNhwcArgs a)
+{
+    __shared__ double red[2][4];
+    int o = 0;
+    while ((int)blockIdx.x >= a.lv.bblk_off[o + 1]) ++o;
+    const int l = a.lv.L - 1 - o;
+    const int A = a.lv.A, W = a.lv.W[l];
+    const int64_t HW = (int64_t)a.lv.H[l] * W, N = (int64_t)a.lv.B * HW * A;
+    const int64_t n = (int64_t)(blockIdx.x - a.lv.bblk_off[o]) * 256 + threadIdx.x;   // (b, p, a)
+    double acc_l1 = 0.0, acc_iou = 0.0;
+    if (n < N) {
+        const int64_t pix = n / A;
+        const int an = (int)(n - pix * A);
+        const int p = (int)(pix % HW);
+        const float4 wt4 = reinterpret_cast<const float4 *>(a.bw[l])[n];
+        const float wv[4] = {wt4.x, wt4.y, wt4.z, wt4.w};
+        const bool live = (wv[0] != 0.0f) | (wv[1] != 0.0f) | (wv[2] != 0.0f) | (wv[3] != 0.0f);
+        float g_box[4] = {0.0f, 0.0f, 0.0f, 0.0f}, g_iou = 0.0f;
+        if (live) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(a.reg[l] + pix * a.ps_reg[l] + 4 * an);
+            const float dp[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float4 tq = reinterpret_cast<const float4 *>(a.bt[l])[n];
+            const float dt[4] = {tq.x, tq.y, tq.z, tq.w};
+            const int y = p / W, x = p - y * W;
+            const float sx = (float)(x * a.lv.stride[l]), sy = (float)(y * a.lv.stride[l]);
+            const float *b4 = a.ba.v[l][an];
+            const float anc[4] = {b4[0] + sx, b4[1] + sy, b4[2] + sx, b4[3] + sy};
+            const IouElem q = iou_target_elem(anc, dp, dt, a.means, a.stds);
+            const float xl = a.iou[l][pix * a.ps_iou[l] + an];
+            if (!BWD) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += smooth_l1_val(dp[k] - dt[k], a.beta) * wv[k];
+                acc_l1 = (double)s;
+                acc_iou = (double)(bce_logits_(xl, q.t) * wv[0]);
+            } else {
+                const float gs1 = upstream(a.gin, a.res, a.lv.L, 1, l, a.lw_bbox);
+                const float gs2 = upstream(a.gin, a.res, a.lv.L, 2, l, a.lw_iou);
+                g_iou = ((sigmoidf_(xl) - q.t) * wv[0]) * gs2;
+                float gv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (a.attach) iou_bce_box_grad(q, xl, wv[0], gs2, a.stds, gv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    g_box[k] = (smooth_l1_der(dp[k] - dt[k], a.beta) * wv[k]) * gs1 + gv[k];
+            }
+        }
+        if (BWD) {
+            *reinterpret_cast<float4 *>(a.g_reg[l] + pix * a.pg_reg[l] + 4 * an) =
+                make_float4(g_box[0], g_box[1], g_box[2], g_box[3]);
+            a.g_iou[l][pix * a.pg_iou[l] + an] = g_iou;
+        }
+    }
+    if (!BWD) {
+        const bool any = __syncthreads_or((acc_l1 != 0.0) | (acc_iou != 0.0));
+        if (any) {
+            const double s1 = wave_sum(acc_l1), s2 = wave_sum(acc_iou);
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                const double s = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) +
+                                 red[threadIdx.x][3];
+                if (s != 0.0)
+                    atomicAdd(a.sums + (size_t)((1 + threadIdx.x) * a.lv.L + l) * IA_LOSS_SLOTS +
+                                  (blockIdx.x & kSlotMask), s);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ slots -> losses
 struct FinArgs {
     const double *sums;
@@ -661,6 +854,160 @@ int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, i
         hipLaunchKernelGGL((k_focal_ml<uint16_t, true>), dim3(fgrid), dim3(64), 0, s, fa);
         hipLaunchKernelGGL((k_box_ml<uint16_t, true>), dim3(grid), dim3(256), 0, s, ba);
     } else return IA_E_ARG;
+    return hip_status(hipGetLastError());
+}
+
+
+namespace ia {
+static int fill_levels_nhwc(const ia_head_geom *g, int B, NhwcLevels &lv)
+{
+    if (!g || B < 1) return IA_E_ARG;
+    if (g->num_levels < 1 || g->num_levels > IA_MAX_LEVELS) return IA_E_ARG;
+    if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS || g->num_classes < 4 ||
+        (g->num_classes & 3))
+        return IA_E_ARG;                                  // class quads: C % 4 == 0
+    lv.L = g->num_levels; lv.B = B; lv.A = g->num_anchors; lv.C = g->num_classes;
+    int64_t foff = 0, boff = 0;
+    lv.fblk_off[0] = lv.bblk_off[0] = 0;
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        const bool on = l < lv.L;
+        if (on && (g->H[l] < 1 || g->W[l] < 1)) return IA_E_ARG;
+        lv.H[l] = on ? g->H[l] : 0; lv.W[l] = on ? g->W[l] : 0; lv.stride[l] = on ? g->stride[l] : 0;
+    }
+    for (int o = 0; o < IA_MAX_LEVELS; ++o) {
+        if (o < lv.L) {
+            const int l = lv.L - 1 - o;
+            const int64_t anchors = (int64_t)B * lv.H[l] * lv.W[l] * lv.A;
+            foff += (anchors * (lv.C / 4) + kFocalChunks - 1) / kFocalChunks;
+            boff += (anchors + 255) / 256;
+            if (foff > 2147483647LL || boff > 2147483647LL) return IA_E_ARG;
+        }
+        lv.fblk_off[o + 1] = (int32_t)foff;
+        lv.bblk_off[o + 1] = (int32_t)boff;
+    }
+    return 0;
+}
+
+static int check_strides(const NhwcLevels &lv, const ia_level_pix_strides *st, const ia_level_ptrs *p)
+{
+    for (int l = 0; l < lv.L; ++l) {
+        if (st->cls[l] < (int64_t)lv.A * lv.C || st->reg[l] < (int64_t)lv.A * 4 || st->iou[l] < lv.A)
+            return IA_E_ARG;
+        if ((st->cls[l] & 3) || (st->reg[l] & 3)) return IA_E_ARG;          // 16-byte pieces
+        if (((uintptr_t)p->cls[l] & 15u) || ((uintptr_t)p->reg[l] & 15u) || ((uintptr_t)p->iou[l] & 3u))
+            return IA_E_ARG;
+    }
+    return 0;
+}
+}  // namespace ia
+
+int ia_head_loss_fwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
+                          const ia_level_pix_strides *strides, int batch, const ia_head_targets *t,
+                          const ia_head_loss_cfg *cfg, void *workspace, size_t workspace_bytes,
+                          float *result, void *stream)
+{
+    using namespace ia;
+    if (!p || !strides || !t || !cfg || !workspace || !result || ((uintptr_t)workspace & 255u))
+        return IA_E_ARG;
+    FocalNhwcArgs fa;
+    int rc = fill_levels_nhwc(g, batch, fa.lv);
+    if (rc) return rc;
+    const int L = fa.lv.L;
+    if (workspace_bytes < sizeof(double) * kNumLoss * (size_t)L * IA_LOSS_SLOTS) return IA_E_WORKSPACE;
+    if (cfg->gamma != 2.0f || !(cfg->beta > 0.0f)) return IA_E_ARG;
+    for (int l = 0; l < L; ++l)
+        if (!p->cls[l] || !p->reg[l] || !p->iou[l] || !t->labels[l] || !t->label_weights[l] ||
+            !t->bbox_targets[l] || !t->bbox_weights[l])
+            return IA_E_ARG;
+    if ((rc = check_strides(fa.lv, strides, p))) return rc;
+    BoxNhwcArgs ba;
+    ba.lv = fa.lv;
+    memcpy(ba.ba.v, g->base_anchors, sizeof(ba.ba.v));
+    double *sums = static_cast<double *>(workspace);
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        const bool on = l < L;
+        fa.cls[l] = on ? (const float *)p->cls[l] : nullptr;
+        fa.ps_cls[l] = on ? strides->cls[l] : 0; fa.ps_grad[l] = 0; fa.grad[l] = nullptr;
+        fa.labels[l] = on ? t->labels[l] : nullptr; fa.lw[l] = on ? t->label_weights[l] : nullptr;
+        ba.reg[l] = on ? (const float *)p->reg[l] : nullptr; ba.iou[l] = on ? (const float *)p->iou[l] : nullptr;
+        ba.ps_reg[l] = on ? strides->reg[l] : 0; ba.ps_iou[l] = on ? strides->iou[l] : 0;
+        ba.pg_reg[l] = ba.pg_iou[l] = 0;
+        ba.bt[l] = on ? t->bbox_targets[l] : nullptr; ba.bw[l] = on ? t->bbox_weights[l] : nullptr;
+        ba.g_reg[l] = ba.g_iou[l] = nullptr;
+    }
+    fa.sums = sums; fa.gin = fa.res = nullptr;
+    fa.big_logits = cfg->exact_large_logits ? 1 : 0;
+    fa.alpha_pos = cfg->alpha;
+    fa.alpha_neg = (float)(1.0 - (double)cfg->alpha);
+    fa.loss_weight = cfg->loss_weight_cls;
+    ba.sums = sums; ba.gin = ba.res = nullptr;
+    for (int k = 0; k < 4; ++k) { ba.means[k] = g->means[k]; ba.stds[k] = g->stds[k]; }
+    ba.beta = cfg->beta; ba.lw_bbox = cfg->loss_weight_bbox; ba.lw_iou = 1.0f;
+    ba.attach = cfg->attach_iou_target ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * kNumLoss * (size_t)L * IA_LOSS_SLOTS, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_focal_nhwc<false>), dim3((unsigned)fa.lv.fblk_off[L]), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL((k_box_nhwc<false>), dim3((unsigned)fa.lv.bblk_off[L]), dim3(256), 0, s, ba);
+    FinArgs f;
+    f.sums = sums; f.counts = t->counts; f.avg_dev = t->avg_factor_dev; f.avg_host = t->avg_factor;
+    if (!f.counts && !f.avg_dev && !(f.avg_host > 0.0f)) return IA_E_ARG;
+    f.lw[0] = cfg->loss_weight_cls; f.lw[1] = cfg->loss_weight_bbox; f.lw[2] = 1.0f;
+    f.L = L; f.B = batch; f.res = result;
+    hipLaunchKernelGGL(k_headloss_finalize, dim3(1), dim3(64), 0, s, f);
+    return hip_status(hipGetLastError());
+}
+
+int ia_head_loss_bwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
+                          const ia_level_pix_strides *strides, int batch, const ia_head_targets *t,
+                          const ia_head_loss_cfg *cfg, const float *result, const float *grad_result,
+                          const ia_level_ptrs *grads, const ia_level_pix_strides *grad_strides,
+                          void *stream)
+{
+    using namespace ia;
+    if (!p || !strides || !t || !cfg || !result || !grad_result || !grads || !grad_strides)
+        return IA_E_ARG;
+    FocalNhwcArgs fa;
+    int rc = fill_levels_nhwc(g, batch, fa.lv);
+    if (rc) return rc;
+    const int L = fa.lv.L;
+    if (cfg->gamma != 2.0f || !(cfg->beta > 0.0f)) return IA_E_ARG;
+    for (int l = 0; l < L; ++l)
+        if (!p->cls[l] || !p->reg[l] || !p->iou[l] || !t->labels[l] || !t->label_weights[l] ||
+            !t->bbox_targets[l] || !t->bbox_weights[l] || !grads->cls[l] || !grads->reg[l] ||
+            !grads->iou[l])
+            return IA_E_ARG;
+    if ((rc = check_strides(fa.lv, strides, p)) || (rc = check_strides(fa.lv, grad_strides, grads)))
+        return rc;
+    BoxNhwcArgs ba;
+    ba.lv = fa.lv;
+    memcpy(ba.ba.v, g->base_anchors, sizeof(ba.ba.v));
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        const bool on = l < L;
+        fa.cls[l] = on ? (const float *)p->cls[l] : nullptr;
+        fa.ps_cls[l] = on ? strides->cls[l] : 0;
+        fa.grad[l] = on ? (float *)grads->cls[l] : nullptr;
+        fa.ps_grad[l] = on ? grad_strides->cls[l] : 0;
+        fa.labels[l] = on ? t->labels[l] : nullptr; fa.lw[l] = on ? t->label_weights[l] : nullptr;
+        ba.reg[l] = on ? (const float *)p->reg[l] : nullptr; ba.iou[l] = on ? (const float *)p->iou[l] : nullptr;
+        ba.ps_reg[l] = on ? strides->reg[l] : 0; ba.ps_iou[l] = on ? strides->iou[l] : 0;
+        ba.pg_reg[l] = on ? grad_strides->reg[l] : 0; ba.pg_iou[l] = on ? grad_strides->iou[l] : 0;
+        ba.bt[l] = on ? t->bbox_targets[l] : nullptr; ba.bw[l] = on ? t->bbox_weights[l] : nullptr;
+        ba.g_reg[l] = on ? (float *)grads->reg[l] : nullptr;
+        ba.g_iou[l] = on ? (float *)grads->iou[l] : nullptr;
+    }
+    fa.sums = nullptr; fa.gin = grad_result; fa.res = result;
+    fa.big_logits = 0;
+    fa.alpha_pos = cfg->alpha;
+    fa.alpha_neg = (float)(1.0 - (double)cfg->alpha);
+    fa.loss_weight = cfg->loss_weight_cls;
+    ba.sums = nullptr; ba.gin = grad_result; ba.res = result;
+    for (int k = 0; k < 4; ++k) { ba.means[k] = g->means[k]; ba.stds[k] = g->stds[k]; }
+    ba.beta = cfg->beta; ba.lw_bbox = cfg->loss_weight_bbox; ba.lw_iou = 1.0f;
+    ba.attach = cfg->attach_iou_target ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_focal_nhwc<true>), dim3((unsigned)fa.lv.fblk_off[L]), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL((k_box_nhwc<true>), dim3((unsigned)fa.lv.bblk_off[L]), dim3(256), 0, s, ba);
     return hip_status(hipGetLastError());
 }
 

@@ -35,6 +35,11 @@ class LevelPtrs(C.Structure):
                 ('iou', C.c_void_p * IA_MAX_LEVELS)]
 
 
+class LevelPixStrides(C.Structure):
+    _fields_ = [('cls', C.c_int64 * IA_MAX_LEVELS), ('reg', C.c_int64 * IA_MAX_LEVELS),
+                ('iou', C.c_int64 * IA_MAX_LEVELS)]
+
+
 class HeadTargets(C.Structure):
     _fields_ = [('labels', C.c_void_p * IA_MAX_LEVELS), ('label_weights', C.c_void_p * IA_MAX_LEVELS),
                 ('bbox_targets', C.c_void_p * IA_MAX_LEVELS),
@@ -136,6 +141,11 @@ SIGNATURES = {
                               _sz, _vp, _vp]),
     'ia_head_loss_bwd': (_i, [_G, _P, _i, _i, C.POINTER(HeadTargets), C.POINTER(HeadLossCfg), _vp,
                               _vp, _vp, _P, _vp]),
+    'ia_head_loss_fwd_nhwc': (_i, [_G, _P, C.POINTER(LevelPixStrides), _i, C.POINTER(HeadTargets),
+                                   C.POINTER(HeadLossCfg), _vp, _sz, _vp, _vp]),
+    'ia_head_loss_bwd_nhwc': (_i, [_G, _P, C.POINTER(LevelPixStrides), _i, C.POINTER(HeadTargets),
+                                   C.POINTER(HeadLossCfg), _vp, _vp, _P, C.POINTER(LevelPixStrides),
+                                   _vp]),
     'ia_grouped_conv3x3_pack': (_i, [_vp, _vp, _i, _i, _vp]),
     'ia_grouped_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),

@@ -934,10 +934,145 @@ class _HeadLossFn(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+def _pix_stride(t):
+    """pixel stride (elements) of a channels-last-like (B, C, H, W) tensor -- channels-last itself,
+    or a channel slice of a channels-last tensor -- else None"""
+    if t.dim() != 4 or not t.is_cuda or t.dtype != torch.float32:
+        return None
+    B, Cn, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if Cn > 1 and sc != 1:
+        return None
+    ps = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else Cn))
+    if ps < Cn or (W > 1 and sw != ps) or (H > 1 and sh != W * ps) or (B > 1 and sb != H * W * ps):
+        return None
+    return int(ps)
+
+
+def _shared_base(r, i):
+    """reg / iou as channel slices of ONE channels-last tensor (the training head's 48-channel
+    output): -> that tensor, else None"""
+    b = r._base
+    if b is None or b is not i._base or b.dim() != 4 or b.dtype != torch.float32 \
+            or not b.is_contiguous(memory_format=torch.channels_last) \
+            or tuple(b.shape[2:]) != tuple(r.shape[2:]) or b.shape[0] != r.shape[0]:
+        return None
+    ps = b.shape[1]
+    if _pix_stride(r) != ps or _pix_stride(i) != ps:
+        return None
+    return b
+
+
+class _HeadLossNhwcFn(torch.autograd.Function):
+    """the three losses of every level on channels-last head outputs (csrc/headloss.hip,
+    k_focal_nhwc / k_box_nhwc): no layout copies, no packed targets.  Inputs: cls[L], then either
+    reg[L] + iou[L], or (fused) the L wider tensors reg / iou are channel slices of -- their
+    gradient is then written in place into one tensor of that shape."""
+
+    @staticmethod
+    def forward(ctx, geom, targets, cfg, views, *outs):
+        L = geom.L
+        cls = list(outs[:L])
+        fused = views is not None
+        if fused:
+            bases = list(outs[L:2 * L])
+            reg, iou = views
+        else:
+            bases = None
+            reg, iou = list(outs[L:2 * L]), list(outs[2 * L:3 * L])
+        B, dev = cls[0].shape[0], cls[0].device
+        p, st = LevelPtrs(), _lib.LevelPixStrides()
+        for l in range(L):
+            p.cls[l], p.reg[l], p.iou[l] = cls[l].data_ptr(), reg[l].data_ptr(), iou[l].data_ptr()
+            st.cls[l], st.reg[l], st.iou[l] = _pix_stride(cls[l]), _pix_stride(reg[l]), _pix_stride(iou[l])
+        labels, lw, bt, bw, counts, avg = targets
+        labels = [t.contiguous().to(torch.int64) for t in labels]
+        lw = [t.contiguous().to(torch.float32) for t in lw]
+        bt = [t.contiguous().to(torch.float32) for t in bt]
+        bw = [t.contiguous().to(torch.float32) for t in bw]
+        ht = _lib.HeadTargets()
+        for l in range(L):
+            ht.labels[l], ht.label_weights[l] = labels[l].data_ptr(), lw[l].data_ptr()
+            ht.bbox_targets[l], ht.bbox_weights[l] = bt[l].data_ptr(), bw[l].data_ptr()
+        avg_dev = None
+        if counts is not None:
+            ht.counts = counts.data_ptr()
+        elif torch.is_tensor(avg):
+            avg_dev = avg.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+            ht.avg_factor_dev = avg_dev.data_ptr()
+        else:
+            ht.avg_factor = float(avg)
+        hc = _lib.HeadLossCfg(*cfg)
+        res = torch.empty(3 * L + 4, dtype=torch.float32, device=dev)
+        nbytes = 8 * 3 * L * _lib.IA_LOSS_SLOTS
+        ws = _workspace(dev, nbytes)
+        _lib.check(_lib.lib().ia_head_loss_fwd_nhwc(geom.ref(), C.byref(p), C.byref(st), B,
+                                                    C.byref(ht), C.byref(hc), _ptr(ws), nbytes,
+                                                    _ptr(res), _stream()), 'ia_head_loss_fwd_nhwc')
+        ctx.geom, ctx.cfg, ctx.B, ctx.fused = geom, hc, B, fused
+        ctx.keep = (cls, reg, iou, bases, labels, lw, bt, bw, counts, avg_dev, p, st, ht)
+        ctx.res = res
+        ctx.set_materialize_grads(False)
+        return tuple(res[:3 * L + 3].view(3 * L + 3, 1).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cls, reg, iou, bases, labels, lw, bt, bw, counts, avg_dev, p, st, ht = ctx.keep
+        L, dev = ctx.geom.L, cls[0].device
+        z = _zero1(dev)
+        gin = torch.cat([z if g is None else g.detach().reshape(1).to(torch.float32) for g in gs])
+        gp, gst = LevelPtrs(), _lib.LevelPixStrides()
+        cl = torch.channels_last
+        g_cls = [torch.empty(t.shape, dtype=torch.float32, device=dev, memory_format=cl) for t in cls]
+        if ctx.fused:
+            # one gradient tensor per level shaped like the wider tensor; channels beyond reg | iou
+            # (alignment padding) get zero gradient
+            g_base = [torch.empty(b.shape, dtype=torch.float32, device=dev, memory_format=cl)
+                      for b in bases]
+            for l, b in enumerate(bases):
+                if b.shape[1] > reg[l].shape[1] + iou[l].shape[1]:
+                    g_base[l].zero_()
+            for l in range(L):
+                gp.reg[l] = g_base[l].data_ptr() + (reg[l].data_ptr() - bases[l].data_ptr())
+                gp.iou[l] = g_base[l].data_ptr() + (iou[l].data_ptr() - bases[l].data_ptr())
+                gst.reg[l] = gst.iou[l] = bases[l].shape[1]
+            tail = g_base
+        else:
+            g_reg = [torch.empty(t.shape, dtype=torch.float32, device=dev, memory_format=cl) for t in reg]
+            g_iou = [torch.empty(t.shape, dtype=torch.float32, device=dev, memory_format=cl) for t in iou]
+            for l in range(L):
+                gp.reg[l], gp.iou[l] = g_reg[l].data_ptr(), g_iou[l].data_ptr()
+                gst.reg[l], gst.iou[l] = reg[l].shape[1], iou[l].shape[1]
+            tail = g_reg + g_iou
+        for l in range(L):
+            gp.cls[l], gst.cls[l] = g_cls[l].data_ptr(), cls[l].shape[1]
+        _lib.check(_lib.lib().ia_head_loss_bwd_nhwc(ctx.geom.ref(), C.byref(p), C.byref(st), ctx.B,
+                                                    C.byref(ht), C.byref(ctx.cfg), _ptr(ctx.res),
+                                                    _ptr(gin), C.byref(gp), C.byref(gst), _stream()),
+                   'ia_head_loss_bwd_nhwc')
+        return (None, None, None, None) + tuple(g_cls) + tuple(tail)
+
+
+def _nhwc_route(geom, cls, reg, iou):
+    """-> (views or None, inputs) when every head output is channels-last-like fp32, else None"""
+    if geom.C % 4 or any(_pix_stride(t) is None for t in list(cls) + list(reg) + list(iou)):
+        return None
+    if any((_pix_stride(t) % 4) for t in list(cls) + list(reg)) \
+            or any(t.data_ptr() % 16 for t in list(cls) + list(reg)):
+        return None
+    bases = [_shared_base(r, i) for r, i in zip(reg, iou)]
+    if all(b is not None for b in bases):
+        return (list(reg), list(iou)), list(cls) + bases
+    return None, list(cls) + list(reg) + list(iou)
+
+
 def head_loss(geom, cls, reg, iou, labels, label_weights, bbox_targets, bbox_weights, counts=None,
               avg_factor=None, gamma=2.0, alpha=0.25, loss_weight_cls=1.0, beta=0.11,
-              loss_weight_bbox=1.0, attach_iou_target=True, exact_large_logits=False):
+              loss_weight_bbox=1.0, attach_iou_target=True, exact_large_logits=False,
+              channels_last=None):
     """FocalLoss(gamma=2) + SmoothL1Loss + IoU BCE of every pyramid level in one autograd node.
+    channels_last: None = the channels-last kernels when every head output is channels-last(-like)
+    fp32 (the training head's outputs are), else the NCHW kernels; True / False force a route.
     Normaliser: `counts` ((B,2) of anchor_targets: sum_b max(n_pos_b, 1), stays on the device), else
     `avg_factor` (python number or device scalar).  -> dict of three LevelLosses lists."""
     if counts is None and avg_factor is None:
@@ -949,7 +1084,13 @@ def head_loss(geom, cls, reg, iou, labels, label_weights, bbox_targets, bbox_wei
            int(bool(attach_iou_target)), int(bool(exact_large_logits)))
     targets = (list(labels), list(label_weights), list(bbox_targets), list(bbox_weights), counts,
                avg_factor)
-    flat = _HeadLossFn.apply(geom, targets, cfg, *(list(cls) + list(reg) + list(iou)))
+    route = _nhwc_route(geom, cls, reg, iou) if channels_last is not False else None
+    if route is not None:
+        flat = _HeadLossNhwcFn.apply(geom, targets, cfg, route[0], *route[1])
+    elif channels_last is True:
+        raise ValueError('channels_last=True needs channels-last fp32 head outputs, C % 4 == 0')
+    else:
+        flat = _HeadLossFn.apply(geom, targets, cfg, *(list(cls) + list(reg) + list(iou)))
     out = {}
     for k, name in enumerate(('loss_cls', 'loss_bbox', 'losses_iou')):
         lst = LevelLosses(flat[k * L:(k + 1) * L])

