@@ -470,7 +470,15 @@ __global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
     const int A = a.lv.A, C = a.lv.C, C4 = C >> 2, AC4 = A * C4;
     const int64_t HW = (int64_t)a.lv.H[l] * a.lv.W[l];
     const int64_t nchunks = (int64_t)a.lv.B * HW * AC4;
-    const int64_t base = (int64_t)(blockIdx.x - a.lv.fblk_off[o]) * kFocalChunks + threadIdx.x;
+    // chunk -> (pixel, anchor, class quad) without per-chunk integer divisions (a 64-bit division
+    // per chunk cost as many issue slots as the loss math of its four elements): one division
+    // per workgroup for its first chunk, then offsets < AC4 + 1024 divided through the float
+    // reciprocal ((n + 0.5) / d is at least 0.5 / d away from an integer, far above fp32
+    // rounding for n, d < 2^14)
+    const int64_t base0 = (int64_t)(blockIdx.x - a.lv.fblk_off[o]) * kFocalChunks;
+    const int64_t pix0 = base0 / AC4;
+    const int r0 = (int)(base0 - pix0 * AC4);
+    const float inv_ac4 = 1.0f / (float)AC4, inv_c4 = 1.0f / (float)C4;
     const float gs = BWD ? upstream(a.gin, a.res, a.lv.L, 0, l, a.loss_weight) : 1.0f;
     const float *cls = a.cls[l];
     const int64_t ps = a.ps_cls[l], pg = BWD ? a.ps_grad[l] : 0;
@@ -481,13 +489,16 @@ __global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
     bool on[kFocalU];
 #pragma unroll
     for (int u = 0; u < kFocalU; ++u) {
-        int64_t ch = base + 256 * u;
-        on[u] = ch < nchunks;
-        if (!on[u]) ch = nchunks - 1;                       // clamped: loads unconditional
-        const int64_t pix = ch / AC4;                       // (b, p)
-        const int r = (int)(ch - pix * AC4);                // a * C4 + class quad
-        anchor[u] = pix * A + r / C4;
-        cq[u] = r % C4;
+        int j = (int)threadIdx.x + 256 * u;
+        on[u] = base0 + j < nchunks;
+        if (!on[u]) j = (int)(nchunks - 1 - base0);         // clamped: loads unconditional
+        const int rr = r0 + j;
+        const int dp = (int)(((float)rr + 0.5f) * inv_ac4);
+        const int64_t pix = pix0 + dp;                      // (b, p)
+        const int r = rr - dp * AC4;                        // a * C4 + class quad
+        const int an = (int)(((float)r + 0.5f) * inv_c4);
+        anchor[u] = pix * A + an;
+        cq[u] = r - an * C4;
         typedef float F4 __attribute__((ext_vector_type(4)));
         const F4 q = __builtin_nontemporal_load(reinterpret_cast<const F4 *>(cls + pix * ps + 4 * r));
         v[u] = make_float4(q.x, q.y, q.z, q.w);
@@ -509,21 +520,31 @@ __global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
             rq[k] = __builtin_amdgcn_rcpf(sk);
             lg[k] = __builtin_amdgcn_logf(sk);
         }
-        const int jp = lab - 1 - 4 * cq[u];                 // the positive class's slot in this quad
+        // every element in its negative form first (no per-element select: the forward kernel is
+        // VALU-bound -- 3 transcendentals + the plain operations of an element are ~60 us of
+        // issue time at batch 4, against 41 us of HBM time); the one positive element of a
+        // positive anchor (0.1 % of the anchors) is corrected after, under a rare branch
         float o4[4], acc = 0.0f, fix = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             Sig g; g.q = rq[k]; g.lg = lg[k]; g.p = t[k] * rq[k];
-            if (k == jp) {
-                if (BWD) o4[k] = pos_der(g, __builtin_fminf(x[k], kXMax)) * wp;
-                else fix = pos_val(g, __builtin_fminf(x[k], kXMax)) * wp;
-            } else {
-                if (BWD) o4[k] = neg_der(g) * wn;
-                else {
-                    acc += neg_val2(g);
-                    if (a.big_logits && x[k] > kXMax) fix += (x[k] - kXMax) * wn;   // exact tail
+            if (BWD) o4[k] = neg_der(g) * wn;
+            else acc += neg_val2(g);
+        }
+        const int jp = lab - 1 - 4 * cq[u];                 // the positive class's slot in this quad
+        if (jp >= 0 && jp < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k == jp) {
+                    Sig g; g.q = rq[k]; g.lg = lg[k]; g.p = t[k] * rq[k];
+                    if (BWD) o4[k] = pos_der(g, __builtin_fminf(x[k], kXMax)) * wp;
+                    else { acc -= neg_val2(g); fix = pos_val(g, __builtin_fminf(x[k], kXMax)) * wp; }
                 }
-            }
+        }
+        if (!BWD && a.big_logits) {                         // exact tail, on request (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x[k] > kXMax && k != jp) fix += (x[k] - kXMax) * wn;
         }
         if (BWD) {
             if (on[u]) *reinterpret_cast<float4 *>(a.grad[l] + goff[u]) = make_float4(o4[0], o4[1], o4[2], o4[3]);
@@ -866,6 +887,7 @@ static int fill_levels_nhwc(const ia_head_geom *g, int B, NhwcLevels &lv)
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS || g->num_classes < 4 ||
         (g->num_classes & 3))
         return IA_E_ARG;                                  // class quads: C % 4 == 0
+    if ((int64_t)g->num_anchors * (g->num_classes / 4) > 8192) return IA_E_ARG;   // float-reciprocal division
     lv.L = g->num_levels; lv.B = B; lv.A = g->num_anchors; lv.C = g->num_classes;
     int64_t foff = 0, boff = 0;
     lv.fblk_off[0] = lv.bblk_off[0] = 0;

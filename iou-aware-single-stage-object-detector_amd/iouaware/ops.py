@@ -1055,7 +1055,8 @@ class _HeadLossNhwcFn(torch.autograd.Function):
 
 def _nhwc_route(geom, cls, reg, iou):
     """-> (views or None, inputs) when every head output is channels-last-like fp32, else None"""
-    if geom.C % 4 or any(_pix_stride(t) is None for t in list(cls) + list(reg) + list(iou)):
+    if geom.C % 4 or geom.A * (geom.C // 4) > 8192 \
+            or any(_pix_stride(t) is None for t in list(cls) + list(reg) + list(iou)):
         return None
     if any((_pix_stride(t) % 4) for t in list(cls) + list(reg)) \
             or any(t.data_ptr() % 16 for t in list(cls) + list(reg)):

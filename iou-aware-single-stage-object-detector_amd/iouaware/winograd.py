@@ -179,7 +179,9 @@ class WinogradConv3x3(object):
     def __call__(self, x, pre=None):
         """pre = (scale, shift, relu): x is the raw output of the convolution in front, its folded
         BatchNorm / ReLU is applied while the input transform loads it"""
-        key = (x.shape[0], tuple(x.shape[-2:]), x.device)
+        # the plan owns scratch buffers (V, M): one per stream, so forwards on different streams
+        # do not share them
+        key = (x.shape[0], tuple(x.shape[-2:]), x.device, torch.cuda.current_stream().cuda_stream)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = _Plan([tuple(x.shape[-2:])], x.shape[0], x.device)
@@ -247,7 +249,7 @@ class WinogradHead(object):
         """feats: per-level (B, Cin, H, W) channels-last fp32 -> (cls[L], reg[L], iou[L])"""
         B = feats[0].shape[0]
         sizes = [tuple(x.shape[-2:]) for x in feats]
-        key = (B, tuple(sizes), feats[0].device)
+        key = (B, tuple(sizes), feats[0].device, torch.cuda.current_stream().cuda_stream)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = _Plan(sizes, B, feats[0].device)

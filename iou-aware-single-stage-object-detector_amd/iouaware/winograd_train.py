@@ -33,7 +33,8 @@ from . import winograd as W
 
 
 def _plan(xs):
-    key = (xs[0].shape[0], tuple(tuple(x.shape[-2:]) for x in xs), xs[0].device)
+    key = (xs[0].shape[0], tuple(tuple(x.shape[-2:]) for x in xs), xs[0].device,
+           torch.cuda.current_stream().cuda_stream)
     plan = _PLANS.get(key)
     if plan is None:
         plan = _PLANS[key] = W._Plan([tuple(x.shape[-2:]) for x in xs], xs[0].shape[0],

@@ -9,6 +9,8 @@ import torch, bench, iouaware
 from iouaware.config import ConfigDict
 from iouaware.fuse import fuse_inference
 torch.backends.cudnn.benchmark = True
+from iouaware import ops
+ops.gemm_tuning('all')
 cfg = ConfigDict(bench.MODEL); cfg.backbone.update(dict(depth=101))
 torch.manual_seed(0)
 m = iouaware.build_detector(cfg, test_cfg=ConfigDict(bench.TEST_CFG)).cuda().eval()

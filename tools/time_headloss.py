@@ -3,7 +3,7 @@ outputs): device target assignment + the three losses of all levels forward + pa
 backward.  Prints wall per iteration (HIP events); under rocprofv3 the kernel trace is reduced by
 tools/summarize_trace.py with the marker `k_box_ml<float, true>` (last kernel of an iteration).
 
-    python tools/time_headloss.py [B] [per_level]
+    python tools/time_headloss.py [B] [per_level | nhwc]
 """
 import os
 import sys
@@ -20,6 +20,8 @@ import bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 per_level = len(sys.argv) > 2 and sys.argv[2] == 'per_level'
+nhwc = len(sys.argv) > 2 and sys.argv[2] == 'nhwc'      # channels-last outputs, reg | iou as slices of one
+                                                         # 48-channel tensor: what the training head produces
 TRAIN_CFG = ConfigDict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4,
                                      min_pos_iou=0, ignore_iof_thr=-1), allowed_border=-1,
                        pos_weight=-1, debug=False)
@@ -29,6 +31,15 @@ head = IoUawareRetinaHead(**kw).cuda()
 head.fuse_levels = not per_level
 cls, reg, iou = synth.head_outputs(3, B, 800, 1344, 'A')
 outs = [[torch.from_numpy(t).cuda().requires_grad_(True) for t in x] for x in (cls, reg, iou)]
+leaves = [t for x in outs for t in x]
+if nhwc:
+    cl = torch.channels_last
+    c = [t.detach().contiguous(memory_format=cl).requires_grad_(True) for t in outs[0]]
+    ri = [torch.cat([r.detach(), i.detach(), r.detach()[:, :3] * 0], 1).contiguous(memory_format=cl)
+          .requires_grad_(True) for r, i in zip(outs[1], outs[2])]
+    n_reg, n_iou = outs[1][0].shape[1], outs[2][0].shape[1]
+    outs = [c, [t[:, :n_reg] for t in ri], [t[:, n_reg:n_reg + n_iou] for t in ri]]
+    leaves = c + ri
 gts, gls = synth.train_targets(5, B, 800, 1333, max_gt=20)
 gtb = [torch.from_numpy(x).cuda() for x in gts]
 gtl = [torch.from_numpy(x).cuda() for x in gls]
@@ -43,9 +54,8 @@ def it():
         with torch.no_grad():
             head.loss(*outs, gtb, gtl, metas, TRAIN_CFG)
         return
-    for x in outs:
-        for t in x:
-            t.grad = None
+    for t in leaves:
+        t.grad = None
     losses = head.loss(*outs, gtb, gtl, metas, TRAIN_CFG)
     loss, _ = parse_losses(losses)
     loss.backward()

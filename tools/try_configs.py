@@ -8,6 +8,8 @@ import torch, bench, iouaware
 from iouaware.config import ConfigDict
 from iouaware.fuse import fuse_inference
 torch.backends.cudnn.benchmark = True
+from iouaware import ops
+ops.gemm_tuning('all')
 def run(name, backbone, B, dtype):
     cfg = ConfigDict(bench.MODEL); cfg.backbone.update(backbone)
     torch.manual_seed(0)
