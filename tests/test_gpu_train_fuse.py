@@ -1,6 +1,7 @@
 """GPU: the training route of the bottlenecks / FPN (iouaware/train_fuse.py: GEMM and Winograd
 autograd nodes, eval-mode BatchNorm folded differentiably) against the plain nn.Module forward
 (MIOpen + BatchNorm + autograd): outputs, input gradients and every parameter gradient."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -224,3 +225,47 @@ def test_whole_detector_training_iteration_fused_vs_module():
     assert worst[0] < 5e-2, worst
     total = torch.cat([g.flatten() for g in ga.values()]), torch.cat([gb[k].flatten() for k in ga])
     assert _rel2(*total) < 5e-3
+
+
+def test_eval_after_training_steps_sees_the_updated_parameters():
+    """fused training route -> optimizer steps -> model.eval(): the inference route's folded /
+    transformed weight copies are derived again from the updated parameters (stamp check), so the
+    fused eval forward equals the plain modules' eval forward on the trained weights"""
+    import iouaware
+    import bench
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference, unfuse_inference
+    from iouaware.train import build_optimizer, train_step
+    torch.manual_seed(0)
+    model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=ConfigDict(bench.TRAIN_CFG),
+                                    test_cfg=ConfigDict(bench.TEST_CFG))
+    state = model.state_dict()
+    synth.e2e_fill_state(state, 7)
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    fuse_inference(model, winograd=True, train=True)
+    model = model.to(memory_format=torch.channels_last)
+    opt = build_optimizer(model, dict(type='SGD', lr=0.001, momentum=0.9, weight_decay=0.0001))
+    gts, gls = synth.train_targets(11, 2, 250, 317, max_gt=6)
+    gtb = [torch.from_numpy(x).cuda() for x in gts]
+    gtl = [torch.from_numpy(x).cuda() for x in gls]
+    metas = [synth.img_meta(250, 317, 256, 320) for _ in range(2)]
+    img = torch.from_numpy(synth.e2e_image(3, 2, 256, 320, 250, 317)).cuda() \
+        .contiguous(memory_format=torch.channels_last)
+    model.eval()
+    with torch.no_grad():
+        before = [t.clone() for t in model.forward_head(img)[0]]      # folds at the initial weights
+    model.train()
+    first = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+    for _ in range(2):
+        last = train_step(model, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+    assert np.isfinite(first['loss']) and np.isfinite(last['loss'])
+    model.eval()
+    with torch.no_grad():
+        fused = model.forward_head(img)
+        unfuse_inference(model)
+        plain = model.forward_head(img)
+    assert _rel(fused[0][0], before[0]) > 1e-4                         # the weights did move
+    for a, b in zip(fused, plain):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and _rel(x, y) < 1e-4
