@@ -9,6 +9,8 @@ import torch, bench, iouaware
 from iouaware.config import ConfigDict
 from iouaware.fuse import fuse_inference
 torch.backends.cudnn.benchmark = True
+from iouaware import ops
+ops.gemm_tuning('all')
 cfg = ConfigDict(bench.MODEL); cfg.backbone.update(dict(type='ResNeXt', depth=101, groups=64, base_width=4))
 torch.manual_seed(0)
 m = iouaware.build_detector(cfg, test_cfg=ConfigDict(bench.TEST_CFG)).cuda().eval()
@@ -23,4 +25,4 @@ PY
 python /tmp/x101.py 3 > /dev/null 2>&1
 rm -rf /tmp/px
 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -- python /tmp/x101.py 7 > /tmp/px.log 2>&1
-python $ROOT/tools/summarize_trace.py /tmp/px/*/*_kernel_trace.csv --steps 3 --marker "ia::k_lazy_greedy" | head -16 | cut -c1-150
+python $ROOT/tools/summarize_trace.py /tmp/px/*/*_kernel_trace.csv --steps 3 --marker "ia::k_lazy_greedy" --top 24 > /tmp/x101_sum.txt; (head -26; tail -10) < /tmp/x101_sum.txt | cut -c1-150
