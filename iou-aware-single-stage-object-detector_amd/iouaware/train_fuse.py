@@ -113,6 +113,41 @@ def conv1x1(x, w_nk, bias=None, identity=None, relu=False):
     return Conv1x1.apply(x, w_nk, bias, identity, relu)
 
 
+class Conv1x1Fork(torch.autograd.Function):
+    """conv1 of a bottleneck at the residual fork: (relu?(x . w^T + bias), x) -- x is handed on as
+    the block's identity branch, so that BOTH gradients of the block input arrive in this node
+    and the sum `dx = g . w + d_identity` rides in the input-gradient GEMM's epilogue (autograd
+    would add the two contributions in a separate pass over the block's largest tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, w_nk, bias, relu):
+        x = _cl(x)
+        w = w_nk.contiguous()
+        y = ops.linear_bias_act(x, w, None if bias is None else bias.contiguous(), relu=relu,
+                                w_nk=True)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, d_idn):
+        x, w, y = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = dw = db = None
+        if dy is None:                                   # only the identity branch was used
+            return (d_idn if need_x else None), None, None, None
+        g, db = WT.relu_bwd_bias_grad(dy, y if ctx.relu else None, need_b)
+        if need_x:
+            dx = ops.linear_bias_act(g, w, None, residual=None if d_idn is None else _cl(d_idn))
+        if need_w:
+            dw = ops.gemm_tn(_rows(g), _rows(x)) if WGRAD == 'lt' else weight_grad_1x1(_rows(g), _rows(x))
+        return dx, dw, db, None
+
+
+def conv1x1_fork(x, w_nk, bias=None, relu=False):
+    return Conv1x1Fork.apply(x, w_nk, bias, relu)
+
+
 # ------------------------------------------------------------------ eval-mode BatchNorm fold
 def _inv_std(bn):
     key = (bn.running_var.data_ptr(), bn.running_var._version)
@@ -228,7 +263,10 @@ def bottleneck_forward(m, x):
     w1, b1 = fold_bn(m.conv1, m.norm1)
     w2, b2 = fold_bn(m.conv2, m.norm2)
     w3, b3 = fold_bn(m.conv3, m.norm3)
-    out = conv1x1(x, _nk(w1), b1, None, True)
+    if x.requires_grad:
+        out, x = conv1x1_fork(x, _nk(w1), b1, True)     # x: the identity branch from here on
+    else:
+        out = conv1x1(x, _nk(w1), b1, None, True)
     if m.conv2.stride[0] == 1:
         out = WT.wino_conv_levels([out], w2, b2, relu=True)[0]
     else:
