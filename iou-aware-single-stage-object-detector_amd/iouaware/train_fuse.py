@@ -144,6 +144,24 @@ class Conv1x1Fork(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class Subsample(torch.autograd.Function):
+    """x[:, :, ::s, ::s] of a channels-last activation as a channels-last tensor (the input of a
+    strided 1x1 shortcut convolution); the gradient comes back channels-last as well (torch's
+    slice backward builds an NCHW zero tensor that would then be converted)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.shape, ctx.s = tuple(x.shape), int(s)
+        return x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device,
+                         memory_format=torch.channels_last).zero_()
+        dx[:, :, ::ctx.s, ::ctx.s] = g
+        return dx, None
+
+
 def conv1x1_fork(x, w_nk, bias=None, relu=False):
     return Conv1x1Fork.apply(x, w_nk, bias, relu)
 
@@ -276,7 +294,7 @@ def bottleneck_forward(m, x):
     else:
         ds = m.downsample[0]
         wd, bd = fold_bn(ds, m.downsample[1])
-        xs = x if ds.stride[0] == 1 else x[:, :, ::ds.stride[0], ::ds.stride[1]]
+        xs = x if ds.stride[0] == 1 else Subsample.apply(x, ds.stride[0])
         idn = conv1x1(xs, _nk(wd), bd, None, False)
     return conv1x1(out, _nk(w3), b3, idn, True)
 
