@@ -244,6 +244,21 @@ def _nk(w):
     return w.view(w.shape[0], w.shape[1])
 
 
+class _ParamMatrix(torch.autograd.Function):
+    """a (Cout, Cin, 1, 1) PARAMETER as its (Cout, Cin) matrix; the gradient goes back with the
+    parameter's own strides (channels-last parameters: DistributedDataParallel's bucket views
+    follow the parameter's layout and would otherwise restride every gradient)"""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.size, ctx.stride = w.size(), w.stride()
+        return w.view(w.shape[0], w.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous().as_strided(ctx.size, ctx.stride)
+
+
 def _gemm_ok(conv, stride_ok=(1,)):
     return (tuple(conv.kernel_size) == (1, 1) and conv.stride[0] == conv.stride[1]
             and conv.stride[0] in stride_ok and tuple(conv.padding) == (0, 0)
@@ -333,7 +348,7 @@ def fpn_forward(m, inputs):
             idn = F.interpolate(lat[i + 1], scale_factor=2, mode='nearest')
             if tuple(idn.shape[-2:]) != tuple(x.shape[-2:]):
                 raise RuntimeError('FPN levels are not a factor of two apart')   # as the reference
-        lat[i] = conv1x1(x, c.weight.view(c.out_channels, c.in_channels), c.bias, idn, False)
+        lat[i] = conv1x1(x, _ParamMatrix.apply(c.weight), c.bias, idn, False)
     outs = []
     for i in range(n):
         c = m.fpn_convs[i].conv

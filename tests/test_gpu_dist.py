@@ -48,3 +48,55 @@ def test_all_gather_detections_on_rccl_one_rank():
         dist.barrier(device_ids=[0])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ddp_over_the_fused_training_route_on_rccl_one_rank():
+    """DistributedDataParallel (bucketed all-reduce on RCCL, overlapped with backward) around a
+    detector on the fused training route: its reducer hooks fire from the library's autograd
+    nodes, and with one rank the gradients are those of the bare model"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    import bench
+    import iouaware
+    import synth
+    from iouaware import dist as idist
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    from iouaware.train import parse_losses
+    from torch.nn.parallel import DistributedDataParallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0',
+                      WORLD_SIZE='1', LOCAL_RANK='0')
+    idist.init_dist('pytorch', backend='nccl')
+    try:
+        gts, gls = synth.train_targets(11, 2, 250, 317, max_gt=6)
+        gtb = [torch.from_numpy(x).cuda() for x in gts]
+        gtl = [torch.from_numpy(x).cuda() for x in gls]
+        metas = [synth.img_meta(250, 317, 256, 320) for _ in range(2)]
+        img = torch.from_numpy(synth.e2e_image(3, 2, 256, 320, 250, 317)).cuda() \
+            .contiguous(memory_format=torch.channels_last)
+        grads = {}
+        for mode in ('bare', 'ddp'):
+            torch.manual_seed(0)
+            model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=ConfigDict(bench.TRAIN_CFG),
+                                            test_cfg=ConfigDict(bench.TEST_CFG))
+            state = model.state_dict()
+            synth.e2e_fill_state(state, 7)
+            model.load_state_dict(state)
+            model = model.cuda().train()
+            fuse_inference(model, winograd=True, train=True)
+            model = model.to(memory_format=torch.channels_last)
+            net = DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False) \
+                if mode == 'ddp' else model
+            loss, _ = parse_losses(net(img, metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl))
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters() if p.requires_grad}
+            assert all(g is not None for g in grads[mode].values())
+        assert set(grads['bare']) == set(grads['ddp'])
+        a = torch.cat([grads['ddp'][k].flatten() for k in grads['bare']])
+        b = torch.cat([g.flatten() for g in grads['bare'].values()])
+        # (norm-wise: the GEMM kernels are chosen by timing per process state, ReLU masks may flip)
+        assert float((a - b).norm() / b.norm()) < 5e-3
+    finally:
+        dist.destroy_process_group()

@@ -214,7 +214,7 @@ def test_whole_detector_training_iteration_fused_vs_module():
         losses = model(x, metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
         loss, logv = parse_losses(losses)
         loss.backward()
-        res[mode] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters()
+        res[mode] = (float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()
                                    if p.grad is not None})
     (la, ga), (lb, gb) = res['fused'], res['ref']
     assert abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
