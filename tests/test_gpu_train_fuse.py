@@ -181,20 +181,23 @@ def test_frozen_block_takes_the_inference_route_under_grad_mode():
     assert not y.requires_grad and _rel(y, ref) < 1e-4
 
 
-def test_whole_detector_training_iteration_fused_vs_module():
+@pytest.mark.parametrize('B,ph,pw,ih,iw', [(2, 256, 320, 250, 317), (1, 320, 224, 311, 220),
+                                           (3, 192, 192, 192, 190)])
+def test_whole_detector_training_iteration_fused_vs_module(B, ph, pw, ih, iw):
     """R-50 IoU-aware RetinaNet (frozen_stages=1, norm_eval=True), trained-like weights, one
-    iteration at 2 x 256 x 320: losses and all parameter gradients, fused training route vs
-    plain modules"""
+    iteration (landscape batch 2, portrait batch 1, square batch 3: pyramid levels down to 2 x 2
+    positions, partial Winograd tiles everywhere): losses and all parameter gradients, fused
+    training route vs plain modules"""
     import iouaware
     import bench
     from iouaware.config import ConfigDict
     from iouaware.fuse import fuse_inference
     from iouaware.train import parse_losses
-    gts, gls = synth.train_targets(11, 2, 250, 317, max_gt=6)
+    gts, gls = synth.train_targets(11, B, ih, iw, max_gt=6)
     gtb = [torch.from_numpy(x).cuda() for x in gts]
     gtl = [torch.from_numpy(x).cuda() for x in gls]
-    metas = [synth.img_meta(250, 317, 256, 320) for _ in range(2)]
-    img = torch.from_numpy(synth.e2e_image(3, 2, 256, 320, 250, 317)).cuda()
+    metas = [synth.img_meta(ih, iw, ph, pw) for _ in range(B)]
+    img = torch.from_numpy(synth.e2e_image(3, B, ph, pw, ih, iw)).cuda()
     res = {}
     for mode in ('ref', 'fused'):
         torch.manual_seed(0)
