@@ -196,9 +196,22 @@ def test_two_streams_give_the_single_stream_result():
             for r, o in zip(ref, outs):
                 # MIOpen may pick other algorithms on a new stream (its handle is per stream): the
                 # logits then differ in the last bits and near-ties in the top-100 may swap
+                # -> the same detections as SETS: every reference detection has a partner of the
+                # same class within 1e-3, up to three per image lost at the top-100 boundary
                 assert torch.equal(r[3], o[3])
-                assert float((r[1] == o[1]).float().mean()) >= 0.98
-                assert float(((r[0] - o[0]).abs().amax(-1) < 1e-3).float().mean()) >= 0.98
+                for b in range(r[0].shape[0]):
+                    n = int(r[3][b])
+                    rd, rl = r[0][b, :n].cpu().numpy().astype(np.float64), r[1][b, :n].cpu().numpy()
+                    od, ol = o[0][b, :n].cpu().numpy().astype(np.float64), o[1][b, :n].cpu().numpy()
+                    used = np.zeros(n, bool)
+                    missing = 0
+                    for d, l in zip(rd, rl):
+                        ok = (ol == l) & ~used & (np.abs(od - d) <= 1e-3).all(1)
+                        if ok.any():
+                            used[int(np.argmax(ok))] = True
+                        else:
+                            missing += 1
+                    assert missing <= 3, (b, missing, n)
 
 
 @pytest.mark.parametrize('per_cluster', [10, 60, 200])
