@@ -13,7 +13,9 @@ which is a full read+write pass over the activation:
 Parameters and state_dict are untouched (checkpoints still load); the folded
 per-channel scale/shift and weight copies are derived from them by `fuse_inference`
 and derived AGAIN whenever the source tensors change (stamp check in every fused
-forward: checkpoint loads, optimizer steps, `.to()` are all safe after fusing).  Only eval-mode, no-grad,
+forward: checkpoint loads, optimizer steps, `.to()` are all safe after fusing; and after every
+training-mode / grad-mode forward, because torch's fused optimizers update parameters without
+bumping the version counters the stamp reads).  Only eval-mode, no-grad,
 GPU forwards take the fused route; anything else falls back to the module's
 ordinary forward.  BatchNorm in eval mode is y = (x-mean)/sqrt(var+eps)*g + b;
 the folded form x*scale+shift differs from it by rounding only.
@@ -58,15 +60,31 @@ def _stamp(module):
     return tuple(out)
 
 
+def _mark_dirty(module):
+    """this module and every fused module below it: their derived copies must be refreshed before
+    the next inference forward (a training forward ran; see _fast)"""
+    for m in module.modules():
+        if hasattr(m, '_ia_opts'):
+            m._ia_dirty = True
+
+
 def _fast(module, x):
     # no autograd graph to build: grad mode off, or a frozen module (frozen_stages) fed an input
     # that carries no gradient -- then the raw kernels' outputs (requires_grad False) are what
     # eager would have produced as well
     ok = (not module.training) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) \
         and (not torch.is_grad_enabled() or train_fuse.frozen(module, x))
-    if ok and module._ia_stamp != _stamp(module):
+    if not ok:
+        if module.training or torch.is_grad_enabled():
+            # a forward that may be followed by an optimizer step.  The stamp below sees in-place
+            # updates through the tensors' version counters, but torch's FUSED optimizers
+            # (torch.optim.SGD(fused=True), ...) write the parameters without bumping them:
+            # derive the copies again at the next inference forward, whatever the stamp says
+            module._ia_dirty = True
+        return False
+    if getattr(module, '_ia_dirty', False) or module._ia_stamp != _stamp(module):
         _fold(module)              # parameters changed since the fold: derive the copies again
-    return ok
+    return True
 
 
 def _conv_nobias(conv, x):
@@ -221,6 +239,8 @@ def _fpn_forward(self, inputs):
             and t.is_contiguous(memory_format=torch.channels_last)
             for t in inputs[self.start_level:self.backbone_end_level])
     if not ok:
+        if self.training or torch.is_grad_enabled():
+            _mark_dirty(self)          # the ConvModules below are bypassed by the training route
         if _train(self) and train_fuse.fpn_usable(self, inputs):
             return train_fuse.fpn_forward(self, inputs)
         return type(self).forward(self, inputs)
@@ -250,10 +270,12 @@ def _fpn_forward(self, inputs):
 def _head_forward(self, feats):
     w = self._ia_wino
     if (not self.training) and w.usable(feats):
-        if self._ia_stamp != _stamp(self):
+        if getattr(self, '_ia_dirty', False) or self._ia_stamp != _stamp(self):
             _fold(self)
             w = self._ia_wino
         return w(list(feats))
+    if self.training or torch.is_grad_enabled():
+        _mark_dirty(self)              # see _fast: fused optimizers do not bump version counters
     return type(self).forward(self, feats)
 
 
@@ -358,6 +380,7 @@ def _fold(m):
     else:
         return False
     m._ia_stamp = _stamp(m)
+    m._ia_dirty = False
     return True
 
 
@@ -427,7 +450,7 @@ def refresh_fused(model):
 
 def unfuse_inference(model):
     for m in model.modules():
-        for attr in ('_ia_fused', '_ia_wino', '_ia_opts', '_ia_stamp'):
+        for attr in ('_ia_fused', '_ia_wino', '_ia_opts', '_ia_stamp', '_ia_dirty'):
             if hasattr(m, attr):
                 delattr(m, attr)
                 for name in ('forward', '_stem', '_stages'):

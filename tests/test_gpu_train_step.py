@@ -44,3 +44,26 @@ def test_training_iterations_run_and_learn():
     # attached IoU target)
     missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
     assert not missing, missing
+
+
+def test_build_optimizer_fused_sgd_equals_foreach_sgd():
+    """build_optimizer picks torch's fused SGD for CUDA parameters: the same update as the default
+    implementation (momentum, weight decay), to fp32 rounding"""
+    import torch.nn as nn
+    from iouaware.train import build_optimizer
+    torch.manual_seed(0)
+    a = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 4, 1)).cuda()
+    b = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 4, 1)).cuda()
+    b.load_state_dict(a.state_dict())
+    cfg = dict(type='SGD', lr=0.05, momentum=0.9, weight_decay=0.0001)
+    oa = build_optimizer(a, cfg)
+    ob = build_optimizer(b, dict(cfg, foreach=True))
+    assert oa.defaults.get('fused') is True and not ob.defaults.get('fused')
+    x = torch.randn(4, 3, 16, 16, device='cuda')
+    for _ in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(float(q.abs().max()), 1e-12)
