@@ -19,6 +19,8 @@ bash $ROOT/tools/profile_train.sh > $OUT/profile_train.log 2>&1
 cp $ROOT/gpurun_out/profile/train_step_summary.txt $OUT/train_step_summary.txt
 bash $ROOT/tools/collect_wino_pmc.sh > $OUT/wino_pmc.log 2>&1
 cp $ROOT/gpurun_out/pmc/wino_pmc.json $OUT/wino_pmc.json
+bash $ROOT/tools/collect_train_pmc.sh > $OUT/train_pmc.log 2>&1
+cp $ROOT/gpurun_out/pmc/train_pmc.json $OUT/train_pmc.json
 bash $ROOT/tools/profile_config3.sh > $OUT/profile_config3.log 2>&1
 cp $ROOT/gpurun_out/profile/config3_step_summary.txt $OUT/config3_r101_bf16_b16_step_summary.txt 2>/dev/null
 python $ROOT/tools/try_configs.py > $OUT/other_configs.txt 2>&1
