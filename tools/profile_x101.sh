@@ -25,4 +25,4 @@ PY
 python /tmp/x101.py 3 > /dev/null 2>&1
 rm -rf /tmp/px
 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -- python /tmp/x101.py 7 > /tmp/px.log 2>&1
-python $ROOT/tools/summarize_trace.py /tmp/px/*/*_kernel_trace.csv --steps 3 --marker "ia::k_lazy_greedy" --top 24 > /tmp/x101_sum.txt; (head -26; tail -10) < /tmp/x101_sum.txt | cut -c1-150
+python $ROOT/tools/summarize_trace.py /tmp/px/*/*_kernel_trace.csv --steps 3 --marker "ia::k_lazy_greedy" --top 30 > /tmp/x101_sum.txt; mkdir -p $ROOT/gpurun_out/profile; cp /tmp/x101_sum.txt $ROOT/gpurun_out/profile/x101_step_summary.txt; (head -12; tail -10) < /tmp/x101_sum.txt | cut -c1-150
