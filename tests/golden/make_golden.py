@@ -577,6 +577,68 @@ def gen_focal_op():
     save('focal_op', **out)
 
 
+# ---------------------------------------------------------------- training iteration (config 5)
+def gen_train_e2e():
+    """one training iteration of the REFERENCE detector (tools/train.py -> batch_processor ->
+    model(**data) with return_loss=True, mmdet/apis/train.py:38-45; ResNet.train() with
+    norm_eval=True / frozen_stages=1, resnet.py:520-527) on the deterministic trained-like
+    weights: the loss dict, the gradient norm of EVERY trainable parameter and sampled gradient
+    entries of a few of them -- what the fused training route must reproduce."""
+    from mmdet.models import build_detector
+    rcfg = ref_shim.load_config(ref_shim.REF + '/configs/iou_aware_single_stage_detector/'
+                                'iou_aware_retinanet_r50_fpn_1x_4gpu.py')
+    rcfg.model['pretrained'] = None
+    wseed, iseed, B, ph, pw, ih, iw = 7, 3, 2, 256, 320, 250, 317
+    torch.manual_seed(0)
+    ref = build_detector(rcfg.model, train_cfg=rcfg.train_cfg, test_cfg=rcfg.test_cfg)
+    with torch.no_grad():
+        synth.e2e_fill_state(ref.state_dict(), wseed)
+    ref.train()
+    img = synth.e2e_image(iseed, B, ph, pw, ih, iw)
+    gts, gls = synth.train_targets(11, B, ih, iw, max_gt=6)
+    metas = [synth.img_meta(ih, iw, ph, pw, 1.0) for _ in range(B)]
+    losses = ref(torch.from_numpy(img), metas, return_loss=True,
+                 gt_bboxes=[torch.from_numpy(g) for g in gts],
+                 gt_labels=[torch.from_numpy(g) for g in gls])
+    total = sum(sum(v) for k, v in losses.items() if 'loss' in k)
+    total.backward()
+    out = dict(weight_seed=wseed, image_seed=iseed, target_seed=11, batch=B,
+               img=np.array([ih, iw, ph, pw]), img_checksum=synth.checksum([img]),
+               total=np.float64(float(total)))
+    for k, v in losses.items():
+        out[k] = np.array([float(x) for x in v], np.float64)
+    names, norms = [], []
+    rs = np.random.RandomState(5)
+    sampled = ('backbone.layer2.0.conv1.weight', 'backbone.layer2.0.bn1.weight',
+               'backbone.layer2.0.bn1.bias', 'backbone.layer2.0.conv2.weight',
+               'backbone.layer2.0.downsample.0.weight', 'backbone.layer2.3.conv3.weight',
+               'backbone.layer3.2.conv2.weight', 'backbone.layer3.5.bn3.weight',
+               'backbone.layer4.0.conv2.weight', 'backbone.layer4.2.conv1.weight',
+               'neck.lateral_convs.0.conv.weight', 'neck.lateral_convs.2.conv.bias',
+               'neck.fpn_convs.1.conv.weight', 'neck.fpn_convs.3.conv.weight',
+               'bbox_head.cls_convs.0.conv.weight', 'bbox_head.reg_convs.3.conv.bias',
+               'bbox_head.retina_cls.weight', 'bbox_head.retina_reg.weight',
+               'bbox_head.retina_iou.weight', 'bbox_head.retina_cls.bias')
+    for name, p in ref.named_parameters():
+        if p.grad is None:
+            assert not p.requires_grad, name
+            continue
+        g = p.grad.numpy().astype(np.float64).reshape(-1)
+        names.append(name)
+        norms.append(float(np.sqrt((g * g).sum())))
+        if name in sampled:
+            idx = rs.choice(g.size, min(g.size, 2000), replace=False).astype(np.int64)
+            out['gidx/' + name] = idx
+            out['gval/' + name] = g[idx].astype(np.float32)
+    assert all(n in names for n in sampled), [n for n in sampled if n not in names]
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms, np.float64)
+    out['frozen'] = np.array([n for n, p in ref.named_parameters() if not p.requires_grad])
+    print('train_e2e: total %.6f, %d trainable / %d frozen parameters' % (
+        float(total), len(names), len(out['frozen'])), {k: out[k] for k in losses})
+    save('train_e2e', **out)
+
+
 # ---------------------------------------------------------------- model structure (B1, I3)
 def gen_model():
     """parameter names / shapes of the four reference configs (+ the 64x4d backbone of BASELINE
@@ -599,6 +661,6 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e']
     for w in which:
         globals()['gen_' + w]()

@@ -272,3 +272,64 @@ def test_eval_after_training_steps_sees_the_updated_parameters():
     for a, b in zip(fused, plain):
         for x, y in zip(a, b):
             assert x.shape == y.shape and _rel(x, y) < 1e-4
+
+
+@pytest.mark.parametrize('route', ['fused', 'modules'])
+def test_training_iteration_vs_the_reference(route, golden_dir):
+    """tests/golden/train_e2e.npz: one training iteration of the REFERENCE detector (its own
+    forward_train -> loss -> backward on CPU, norm_eval / frozen_stages as configured) on the
+    deterministic trained-like weights.  This build, on the fused training route and on the plain
+    modules: the loss dict to 1e-4, the set of trainable / frozen parameters, every parameter's
+    gradient norm and sampled gradient entries (norm-wise: single ReLU-mask flips, see above)."""
+    import os
+    import iouaware
+    import bench
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    f = np.load(os.path.join(golden_dir, 'train_e2e.npz'))
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    B = int(f['batch'])
+    img_np = synth.e2e_image(int(f['image_seed']), B, ph, pw, ih, iw)
+    assert synth.checksum([img_np]) == int(f['img_checksum'])
+    gts, gls = synth.train_targets(int(f['target_seed']), B, ih, iw, max_gt=6)
+    gtb = [torch.from_numpy(x).cuda() for x in gts]
+    gtl = [torch.from_numpy(x).cuda() for x in gls]
+    metas = [synth.img_meta(ih, iw, ph, pw) for _ in range(B)]
+    torch.manual_seed(0)
+    model = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=ConfigDict(bench.TRAIN_CFG),
+                                    test_cfg=ConfigDict(bench.TEST_CFG))
+    state = model.state_dict()
+    synth.e2e_fill_state(state, int(f['weight_seed']))
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    x = torch.from_numpy(img_np).cuda()
+    if route == 'fused':
+        assert fuse_inference(model, winograd=True, train=True) > 0
+        model = model.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    else:
+        model.bbox_head.train_winograd = False
+    losses = model(x, metas, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+    total = sum(sum(v) for k, v in losses.items() if 'loss' in k)
+    total.sum().backward()
+    for k in ('loss_cls', 'loss_bbox', 'losses_iou'):
+        got = np.array([float(v.detach()) for v in losses[k]])
+        assert np.all(np.abs(got - f[k]) <= 1e-4 * np.maximum(np.abs(f[k]), 1e-3)), (k, got, f[k])
+    assert abs(float(total.detach().sum()) - float(f['total'])) <= 1e-4 * float(f['total'])
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert sorted(k for k, p in model.named_parameters() if not p.requires_grad) == sorted(f['frozen'].tolist())
+    worst = 0.0
+    for name, want in zip(f['grad_names'].tolist(), f['grad_norms']):
+        g = grads[name]
+        assert g is not None, name
+        got = float(g.double().norm())
+        worst = max(worst, abs(got - want) / max(want, 1e-12))
+        assert abs(got - want) <= 5e-3 * max(want, 1e-12), (name, got, want)
+    for key in f.files:
+        if key.startswith('gidx/'):
+            name = key[5:]
+            idx, want = f[key], f['gval/' + name].astype(np.float64)
+            got = grads[name].detach().reshape(-1).cpu().numpy().astype(np.float64)[idx]
+            err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+            assert err <= 1e-2, (name, err)
+    print('worst gradient-norm deviation from the reference: %.2e (%s)' % (worst, route))
