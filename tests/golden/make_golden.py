@@ -548,6 +548,60 @@ def gen_e2e():
         save('e2e_' + name, **out)
 
 
+# ---------------------------------------------------------------- deeper backbones (configs 3, 4)
+E2E_BACKBONES = (
+    # name, reference config file, backbone overrides
+    ('r101', 'iou_aware_retinanet_r101_fpn_1x_4gpu.py', {}),
+    ('x101_32x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', {}),
+    ('x101_64x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', dict(groups=64, base_width=4)),
+)
+
+
+def gen_e2e_backbones():
+    """R-101 (BASELINE config 3's backbone) and ResNeXt-101 32x4d / 64x4d (config 4: the 32x4d
+    config file of the reference with groups=64, as retinanet_x101_64x4d_fpn_1x.py sets them):
+    the reference detector on the trained-like weights, one 256x320 image through its test-time
+    call -- sampled head logits and the per-class result arrays."""
+    from mmdet.models import build_detector
+    for name, cfile, over in E2E_BACKBONES:
+        rcfg = ref_shim.load_config(ref_shim.REF + '/configs/iou_aware_single_stage_detector/' + cfile)
+        rcfg.model['pretrained'] = None
+        rcfg.model['backbone'].update(over)
+        torch.manual_seed(0)
+        ref = build_detector(rcfg.model, train_cfg=rcfg.train_cfg, test_cfg=rcfg.test_cfg).eval()
+        with torch.no_grad():
+            synth.e2e_fill_state(ref.state_dict(), 77)
+        iseed, ph, pw, ih, iw, sf = 9, 256, 320, 250, 317, 1.0
+        img = synth.e2e_image(iseed, 1, ph, pw, ih, iw)
+        meta = dict(ori_shape=(ih, iw, 3), img_shape=(ih, iw, 3), pad_shape=(ph, pw, 3),
+                    scale_factor=sf, flip=False)
+        g, l = synth.e2e_gts(iseed + 100, ih, iw)
+        x = torch.from_numpy(img)
+        with torch.no_grad():
+            cls, reg, iou = ref.bbox_head(ref.extract_feat(x))
+            result = ref(return_loss=False, rescale=True, img=[x], img_meta=[[meta]],
+                         gt_bboxes=[[torch.from_numpy(g)]], gt_labels=[[torch.from_numpy(l)]])
+        out = dict(weight_seed=77, image_seed=iseed, img=np.array([ih, iw, ph, pw]),
+                   scale_factor=np.float32(sf), ori_shape=np.array([ih, iw, 3]), gt_bboxes=g,
+                   gt_labels=l, img_checksum=synth.checksum([img]),
+                   weight_checksum=synth.checksum(
+                       [v.numpy() for k, v in sorted(ref.state_dict().items())]),
+                   backbone=np.array(str(dict(rcfg.model['backbone']))))
+        rs = np.random.RandomState(2000 + iseed)
+        for nm, ts in (('cls', cls), ('reg', reg), ('iou', iou)):
+            for lv, t in enumerate(ts):
+                a = t.numpy().reshape(-1)
+                idx = rs.choice(a.size, min(a.size, 1024), replace=False).astype(np.int64)
+                out['%s_idx_%d' % (nm, lv)] = idx
+                out['%s_val_%d' % (nm, lv)] = a[idx]
+        out['result_counts'] = np.array([r.shape[0] for r in result], np.int32)
+        out['result_cat'] = np.concatenate(result, 0).astype(np.float32)
+        sc = np.sort(out['result_cat'][:, 4].astype(np.float64))[::-1]
+        print('e2e backbone', name, 'dets', int(out['result_counts'].sum()),
+              'min relative score gap %.2e' % float(((sc[:-1] - sc[1:]) / sc[:-1]).min()))
+        save('e2e_backbone_' + name, **out)
+
+
 # ---------------------------------------------------------------- T4 pin
 def gen_focal_op():
     """SigmoidFocalLoss op (T4): the CUDA kernel has no CPU twin in the reference, but for integer
@@ -661,6 +715,6 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones']
     for w in which:
         globals()['gen_' + w]()

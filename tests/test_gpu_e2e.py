@@ -293,6 +293,50 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
         assert total > 0 and matched >= total - 2, (name, matched, total)
 
 
+@pytest.mark.parametrize('path', ['module', 'winograd'])
+@pytest.mark.parametrize('name,backbone', [
+    ('r101', dict(depth=101)),
+    ('x101_32x4d', dict(type='ResNeXt', depth=101, groups=32, base_width=4)),
+    ('x101_64x4d', dict(type='ResNeXt', depth=101, groups=64, base_width=4)),
+])
+def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
+    """tests/golden/e2e_backbone_*.npz (`make_golden.py e2e_backbones`): the REFERENCE detector
+    with an R-101 (config 3) / ResNeXt-101 32x4d / 64x4d (config 4) backbone on the trained-like
+    weights, one image through its test-time call.  This build on the plain modules and on the
+    bench's path (Winograd + hipBLASLt + the grouped-convolution MFMA kernel): sampled head
+    logits within the north star's tolerance, the detections as sets."""
+    f = np.load(os.path.join(golden_dir, 'e2e_backbone_%s.npz' % name))
+    m = _build(backbone)
+    with torch.no_grad():
+        synth.e2e_fill_state(m.state_dict(), int(f['weight_seed']))
+    assert synth.checksum([v.numpy() for k, v in sorted(m.state_dict().items())]) == \
+        int(f['weight_checksum']), 'weights differ from the ones the reference ran with'
+    m = _prepare(m, path)
+    x, meta = _img(f, path)
+    with torch.no_grad():
+        cls, reg, iou = m.forward_head(x)
+    worst = 0.0
+    for nm, ts in (('cls', cls), ('reg', reg), ('iou', iou)):
+        for lv, t in enumerate(ts):
+            a = t.float().contiguous().cpu().numpy().reshape(-1)
+            got = a[f['%s_idx_%d' % (nm, lv)]].astype(np.float64)
+            want = f['%s_val_%d' % (nm, lv)].astype(np.float64)
+            err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+            worst = max(worst, float(err.max()))
+    g = torch.from_numpy(f['gt_bboxes']).cuda()
+    l = torch.from_numpy(f['gt_labels']).cuda()
+    with torch.no_grad():
+        result = m(return_loss=False, rescale=True, img=[x], img_meta=[[meta]],
+                   gt_bboxes=[[g]], gt_labels=[[l]])
+    want = _split(f['result_cat'], f['result_counts'])
+    matched, total, wb, ws = _match_sets(want, result)
+    _REPORT.append('%-10s %-8s head-output err %.2e (x tol %.2f) | dets %d/%d matched within 1e-4 '
+                   '(worst box %.2e, score %.2e)' % (name, path, worst, worst / TOL, matched, total,
+                                                     wb, ws))
+    assert worst <= TOL, (name, path, worst)
+    assert total == 100 and matched >= total - 3, (matched, total)
+
+
 def test_config3_bf16_batch16_post_conv_path(oracle_lib):
     """BASELINE config 3's per-GPU shape: 16 images, bf16 head outputs at 800x1344,
     channels-last.  Image 0 and image 15 bit for bit against the oracle fed the same
