@@ -210,3 +210,40 @@ def test_multiclass_nms_wrapper_validates_its_limits():
     with pytest.raises(ValueError, match='max_num'):
         nms_op.multiclass_nms(torch.zeros(8, 4), torch.zeros(8, 3), 0.05, cfg,
                               _lib.IA_MAX_PER_IMG + 1)
+
+
+@pytest.mark.parametrize('name,backbone', [
+    ('r101', dict(depth=101)),
+    ('x101_32x4d', dict(type='ResNeXt', depth=101, groups=32, base_width=4)),
+    ('x101_64x4d', dict(type='ResNeXt', depth=101, groups=64, base_width=4)),
+])
+def test_deeper_backbones_get_the_reference_fixture_weights(name, backbone):
+    """the name-keyed weight fill gives this build's R-101 / ResNeXt-101 detectors bit for bit the
+    state the reference detector had when tests/golden/e2e_backbone_*.npz was generated: same
+    parameter / buffer names, shapes and order of creation"""
+    import numpy as np
+    import sys
+    sys.path.insert(0, HERE)
+    import synth
+    f = np.load(os.path.join(HERE, 'golden', 'e2e_backbone_%s.npz' % name))
+    torch.manual_seed(0)
+    m = iouaware.build_detector(model_cfg(**backbone), test_cfg=ConfigDict(TEST_CFG)).eval()
+    with torch.no_grad():
+        synth.e2e_fill_state(m.state_dict(), int(f['weight_seed']))
+    assert synth.checksum([v.numpy() for k, v in sorted(m.state_dict().items())]) == \
+        int(f['weight_checksum'])
+
+
+def test_training_fixture_frozen_and_trainable_sets():
+    """tests/golden/train_e2e.npz: the parameters the REFERENCE left without a gradient
+    (frozen_stages=1) and the ones it trained are exactly this build's, by name"""
+    import numpy as np
+    f = np.load(os.path.join(HERE, 'golden', 'train_e2e.npz'))
+    torch.manual_seed(0)
+    m = iouaware.build_detector(model_cfg(), test_cfg=ConfigDict(TEST_CFG)).train()
+    frozen = sorted(k for k, p in m.named_parameters() if not p.requires_grad)
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert frozen == sorted(f['frozen'].tolist())
+    assert trainable == f['grad_names'].tolist()
+    # norm_eval: every BatchNorm stays in eval mode under .train()
+    assert all(not b.training for b in m.modules() if isinstance(b, nn.modules.batchnorm._BatchNorm))
