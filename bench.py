@@ -2,7 +2,8 @@
 """Benchmark of the hot path BASELINE.json names: images/sec at 1333x800,
 IoU-aware RetinaNet R-50-FPN (fp32), batch 8 per GPU on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: bench.py
+                                                         starts N ranks itself, see launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -32,10 +33,20 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   train        -- BASELINE config 5 on this GPU (rank 0, N=1 only): R-50 training iterations at
                   batch 4 (forward, HIP target assignment + loss kernels, backward, grad clip,
                   SGD), img/s, measured after the inference timing.
+  pipeline     -- image -> result, the reference's fps definition (MODEL_ZOO.md:31): uint8 HWC BGR
+                  images resident on the device -> ia_image_transform -> network -> detections ->
+                  D2H + bbox2result, img/s (rank 0, N=1 only).
+  rccl_ranks   -- the size of the process group as the collective library itself counts it
+                  (all-reduce of ones); n_gpus comes from the group, not from --gpus.
+--config r101-bf16 / x101-64x4d run BASELINE configs 3 / 4 through the same path (sub-records
+that belong to config 2 are skipped); --dry-run exercises launcher, process group, timed region
+and the result exchange on CPU with the gloo backend and fake detections (no GPU work).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -76,10 +87,12 @@ TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nm
                 max_per_img=100)
 
 
-def build_model(device, fuse=True, channels_last=False, winograd=True):
+def build_model(device, fuse=True, channels_last=False, winograd=True, backbone=None):
     torch.manual_seed(0)
-    model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=None,
-                                    test_cfg=ConfigDict(TEST_CFG))
+    cfg = ConfigDict(MODEL)
+    if backbone:
+        cfg.backbone.update(backbone)
+    model = iouaware.build_detector(cfg, train_cfg=None, test_cfg=ConfigDict(TEST_CFG))
     model = model.to(device).eval()
     if fuse:
         from iouaware.fuse import fuse_inference
@@ -390,39 +403,233 @@ def rowmax_traffic(kernel):
         return None
 
 
+CONFIGS = {
+    # name -> (BASELINE config, backbone overrides, images per GPU per step, torch dtype name)
+    'r50': ('config 2: IoU-aware RetinaNet R-50-FPN fp32, batch 8', {}, 8, 'float32'),
+    'r101-bf16': ('config 3: IoU-aware RetinaNet R-101-FPN bf16, batch 16 per GPU',
+                  dict(depth=101), 16, 'bfloat16'),
+    'x101-64x4d': ('config 4: IoU-aware RetinaNet X-101-64x4d-FPN fp32, batch 8, grouped 3x3 '
+                   'convolutions on the MFMA kernel (csrc/gconv.hip)',
+                   dict(type='ResNeXt', depth=101, groups=64, base_width=4), 8, 'float32'),
+}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(n, argv, script=None):
+    """Start n ranks of this script, one per GPU, the way the reference's launcher does
+    (tools/dist_test.sh:7-10: `python -m torch.distributed.launch --nproc_per_node=$GPUS ...`,
+    mmdet/apis/env.py:26-31): `torch.distributed.run` sets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* and the ranks rendezvous on 127.0.0.1.  Returns the launcher's exit code; rank 0's
+    JSON line goes to this process's stdout."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL (host driver)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    env['IA_BENCH_LAUNCHED_BY'] = 'bench.py --gpus %d (self-launch)' % n
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           script or os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class DryRunStepper(Stepper):
+    """--dry-run: per-rank fake detections (deterministic in the dataset index) instead of the
+    network -- launcher, process group, timed region, the all-gather and its rank interleave on
+    CPU / gloo, which is everything of the N > 1 path that is not GPU work."""
+    B, M = 3, 100
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.last, self.calls = rank, world, None, 0
+
+    @staticmethod
+    def fake(i, M=100):
+        rs = np.random.RandomState(1000 + i)
+        k = int(rs.randint(0, M + 1))
+        dets = np.zeros((M, 5), np.float32)
+        dets[:k] = rs.uniform(0, 1000, (k, 5)).astype(np.float32)
+        labels = np.full(M, -1, np.int32)
+        labels[:k] = rs.randint(0, 80, k)
+        return dets, labels, k
+
+    def local_detections(self, timed=False):
+        self.calls += 1
+        d, l, n = zip(*[self.fake(j * self.world + self.rank, self.M) for j in range(self.B)])
+        return (torch.from_numpy(np.stack(d)), torch.from_numpy(np.stack(l)),
+                torch.tensor(n, dtype=torch.int32), None, None, None)
+
+    def check(self):
+        D, L, N = self.last[:3]
+        ok = D.shape[0] == self.world * self.B
+        for i in range(self.world * self.B):
+            ed, el, ek = self.fake(i, self.M)
+            ok = ok and bool(np.array_equal(D[i].numpy(), ed) and np.array_equal(L[i].numpy(), el)
+                             and int(N[i]) == ek)
+        return bool(ok)
+
+
+def group_ranks(device):
+    """the size of the process group as the collective library counts it: an all-reduce of ones
+    (RCCL on GPUs), plus the distinct devices behind the ranks"""
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(one)
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, (os.environ.get('LOCAL_RANK', '0'), str(device)))
+    return int(one.item()), sorted(set(ids))
+
+
+def pipeline_record(model, device, batch, steps=5, warmup=2):
+    """image -> result, the reference's fps definition (MODEL_ZOO.md:31 "overall time including
+    data loading, network forwarding and post processing" minus the disk): uint8 HWC BGR images
+    resident on the device -> ia_image_transform (resize to (1333, 800) keep-ratio, normalise,
+    pad to /32: mmdet/datasets/transforms.py:31-50) -> network -> detections -> one D2H copy ->
+    bbox2result (core/bbox/transforms.py:148-166)."""
+    from iouaware.preprocess import ImageTransform
+    g = torch.Generator(device=device).manual_seed(99)
+    # 480 x 800 sources -> scale 1.66625 -> img_shape (800, 1333), pad_shape (800, 1344)
+    raws = [torch.randint(0, 256, (480, 800, 3), dtype=torch.uint8, device=device, generator=g)
+            for _ in range(batch)]
+    tf = ImageTransform(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True,
+                        size_divisor=32)
+    dtype = next(model.parameters()).dtype
+
+    @torch.no_grad()
+    def one():
+        img, ms = tf.batch(raws, (1333, 800), keep_ratio=True, channels_last=True)
+        if dtype != torch.float32:
+            img = img.to(dtype)
+        return model.simple_test_batch(img, ms, rescale=True), ms
+    for _ in range(warmup):
+        res, ms = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, ms = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=round(batch / dt, 2), unit='img/s', ms_per_step=round(dt * 1e3, 3),
+                batch=batch, steps=steps, warmup=warmup,
+                img_shape=list(ms[0]['img_shape']), pad_shape=list(ms[0]['pad_shape']),
+                dets_image0=int(sum(r.shape[0] for r in res[0])),
+                workload='uint8 480x800x3 BGR images on the device -> ia_image_transform '
+                         '(keep-ratio resize to 800x1333, normalise, pad to 800x1344) -> network -> '
+                         'get_bboxes -> one D2H -> bbox2result (80 per-class arrays per image)')
+
+
+STAGE_PREFIXES = ('ia::k_rowmax', 'ia::k_sel', 'ia::k_gather', 'ia::k_dec')
+
+
+def stage_traffic():
+    """HBM bytes per decode-stage pass (all of its kernels) from the committed PMC profile"""
+    path = os.path.join(ROOT, 'profiles', PMC_PROFILE)
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        if prof.get('batch') != BATCH:
+            return None
+        names = prof.get('stage_kernels') or [k for k in prof['kernels']
+                                              if k.startswith(STAGE_PREFIXES)]
+        return int(sum(prof['kernels'][k]['traffic_bytes_per_launch'] for k in names))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None,
+                    help='ranks = GPUs of this node; default: WORLD_SIZE of the launcher, else 1')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='r50',
+                    help='r50 = BASELINE config 2 (the headline); r101-bf16 = config 3; '
+                         'x101-64x4d = config 4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the training sub-record')
+    ap.add_argument('--no-pipeline', action='store_true', help='skip the image -> result sub-record')
     ap.add_argument('--train-find', action='store_true',
                     help='MIOpen find mode for the training sub-record (adds ~8 minutes)')
     ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
     ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
     ap.add_argument('--no-winograd', action='store_true',
                     help='head 3x3 convolutions through MIOpen instead of the Winograd path')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU: fake detections on CPU, gloo backend -- launcher, process group, '
+                         'timed region and result exchange only')
     args = ap.parse_args()
 
+    launched = 'WORLD_SIZE' in os.environ
+    launched_by = os.environ.get('IA_BENCH_LAUNCHED_BY',
+                                 'external launcher' if launched else 'single process')
+    if not launched and (args.gpus or 1) > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here
+        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+            raise SystemExit('bench.py --gpus %d: this node shows %d GPU(s)'
+                             % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit('bench.py --gpus %d inside a launcher with WORLD_SIZE=%d'
+                         % (args.gpus, world))
+    if args.dry_run:
+        device = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    rccl_ranks, rank_devices = 1, None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl')
+        dist.init_process_group(backend='gloo' if args.dry_run else 'nccl')
+        if dist.get_world_size() != world:
+            raise SystemExit('process group of %d ranks, launcher said %d'
+                             % (dist.get_world_size(), world))
+        rccl_ranks, rank_devices = group_ranks(device)
+        if rccl_ranks != world or (not args.dry_run and len(rank_devices) != world):
+            raise SystemExit('collective sees %d ranks on devices %s, expected %d distinct'
+                             % (rccl_ranks, rank_devices, world))
+    sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
+    barrier = dist.barrier if args.dry_run else (lambda: dist.barrier(device_ids=[local_rank]))
+
+    if args.dry_run:
+        stepper = DryRunStepper(rank, world)
+        elapsed = timed_region(lambda: stepper.step(timed=True), args.steps, args.warmup, world,
+                               sync, barrier, device)
+        ok = stepper.check() and stepper.calls == args.steps + args.warmup
+        if rank == 0:
+            print(json.dumps({'metric': 'dry run (no GPU work): launcher + process group + timed '
+                                        'region + result exchange', 'dry_run': True,
+                              'value': round(stepper.B * world * args.steps / elapsed, 3),
+                              'unit': 'fake img/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks,
+                              'backend': 'gloo', 'steps': args.steps, 'warmup': args.warmup,
+                              'exchange_ok': ok, 'launched_by': launched_by}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if not ok:
+            raise SystemExit(1)
+        return
+
     torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
     from iouaware import ops
     ops.gemm_tuning('all')          # library GEMMs: time every supporting kernel per shape (+2 %)
 
+    cfg_name, backbone, batch, dtype_name = CONFIGS[args.config]
+    dtype = getattr(torch, dtype_name)
+    headline = args.config == 'r50'
     model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw,
-                        winograd=not args.no_winograd)
+                        winograd=not args.no_winograd, backbone=backbone)
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    imgs = torch.randn(BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
+    imgs = torch.randn(batch, 3, PAD_H, PAD_W, device=device, generator=g)
+    if dtype != torch.float32:
+        model, imgs = model.to(dtype), imgs.to(dtype)
     if not args.nchw:
         imgs = imgs.contiguous(memory_format=torch.channels_last)
     stepper = Stepper(model, imgs, world)
@@ -437,50 +644,70 @@ def main():
         stepper.collect()
         stepper.rowmax_ms, stepper.stage_ms = [], []
     warm()
-    elapsed = timed_region(step, args.steps, 0, world, torch.cuda.synchronize,
-                           lambda: dist.barrier(device_ids=[local_rank]), device)
+    elapsed = timed_region(step, args.steps, 0, world, sync, barrier, device)
     stepper.collect()
 
-    wino = wino_roofline(stepper) if rank == 0 else None
+    wino = wino_roofline(stepper) if rank == 0 and dtype == torch.float32 else None
     if rank == 0:
-        n_img = BATCH * world * args.steps
+        esz = 4 if dtype == torch.float32 else 2
+        n_img = batch * world * args.steps
         ms_rowmax = float(np.mean(stepper.rowmax_ms))
         ms_stage = float(np.mean(stepper.stage_ms))
-        # the row-max kernel that ran: channels-last head outputs -> k_rowmax_nhwc<float, 20>
-        rm_kernel = 'ia::k_rowmax_nhwc<float, 20>' if stepper.nhwc else 'ia::k_rowmax<float>'
-        achieved = ROWMAX_BYTES_PER_IMAGE * BATCH / (ms_rowmax * 1e-3) / 1e9
-        stage = HEAD_BYTES_PER_IMAGE * BATCH / (ms_stage * 1e-3) / 1e9
+        tname = 'float' if esz == 4 else 'unsigned short'
+        rm_kernel = ('ia::k_rowmax_nhwc<%s, %d>' % (tname, 80 * esz // 16) if stepper.nhwc
+                     else 'ia::k_rowmax<%s>' % tname)
+        rowmax_bytes = ((64512000 + 806400) * esz // 4 + 806400) * batch
+        stage_bytes = HEAD_BYTES_PER_IMAGE * esz // 4 * batch
+        achieved = rowmax_bytes / (ms_rowmax * 1e-3) / 1e9
+        stage = stage_bytes / (ms_stage * 1e-3) / 1e9
         out = {
-            'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN',
+            'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN' if headline else
+                      'images/sec at 1333x800, IoU-aware RetinaNet (%s)' % args.config,
             'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': world,
+            'rccl_ranks': rccl_ranks, 'rank_devices': rank_devices,
+            'launched_by': launched_by,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-            'config': {'workload': 'IoU-aware RetinaNet R-50-FPN fp32, batch 8 per GPU, '
-                                   '3x800x1344 (1333x800 padded to /32), random-init weights, '
-                                   'whole inference path incl. NMS',
-                       'global_batch': BATCH * world, 'parallelism': 'dp%d' % world,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'fp32' if esz == 4 else 'bf16', 'data': 'synthetic',
+            'config': {'workload': ('IoU-aware RetinaNet R-50-FPN fp32, batch 8 per GPU, '
+                                    '3x800x1344 (1333x800 padded to /32), random-init weights, '
+                                    'whole inference path incl. NMS') if headline else
+                                   ('BASELINE %s; 3x800x1344, random-init weights, whole '
+                                    'inference path incl. NMS' % cfg_name),
+                       'global_batch': batch * world, 'parallelism': 'dp%d' % world,
                        'dets_per_image': int(stepper.last[2].float().mean().item())},
-            'roofline': {'bound': 'hbm', 'kernel': rm_kernel.split('::')[1].split('<')[0],
-                         'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': rowmax_traffic(rm_kernel),
+            # SURVEY 8(d)'s unit: the decode stage (row-max + top-k + gather), cls + reg + iou
+            # logits read once = 68 544 000 B per fp32 image; the row-max kernel alone below it
+            'roofline': {'bound': 'hbm',
+                         'kernel': 'decode stage: row-max + top-k select + gather/decode '
+                                   '(SURVEY 8d unit)',
+                         'achieved': round(stage, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(stage / HBM_PEAK_GBS, 4),
+                         'traffic': stage_traffic() if headline else None,
                          'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                           'separate passes, same batch-8 launch)' % PMC_PROFILE,
-                         'bytes_per_launch': ROWMAX_BYTES_PER_IMAGE * BATCH,
-                         'avg_launch_ms': round(ms_rowmax, 4),
-                         'stage': {'kernels': 'row-max + select + gather (SURVEY 8d decode stage)',
-                                   'bytes_per_launch': HEAD_BYTES_PER_IMAGE * BATCH,
-                                   'avg_ms': round(ms_stage, 4), 'achieved': round(stage, 1),
-                                   'frac': round(stage / HBM_PEAK_GBS, 4)},
+                                           'separate passes, same batch-8 launches)' % PMC_PROFILE,
+                         'bytes_per_launch': stage_bytes, 'avg_launch_ms': round(ms_stage, 4),
+                         'rowmax': {'kernel': rm_kernel.split('::')[1].split('<')[0],
+                                    'bytes_per_launch': rowmax_bytes,
+                                    'avg_launch_ms': round(ms_rowmax, 4),
+                                    'achieved': round(achieved, 1),
+                                    'frac': round(achieved / HBM_PEAK_GBS, 4),
+                                    'traffic': rowmax_traffic(rm_kernel) if headline else None},
                          'wino': wino},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and headline and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, stepper)
         else:
             out['cpu_baseline'] = None
-        if world == 1 and not args.no_train:
+        if world == 1 and not args.no_pipeline:
+            try:
+                out['pipeline'] = pipeline_record(model, device, batch)
+            except Exception as exc:
+                out['pipeline'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        else:
+            out['pipeline'] = None
+        if world == 1 and headline and not args.no_train:
             del stepper, model, imgs
             torch.cuda.empty_cache()
             try:

@@ -93,7 +93,18 @@ class SingleStageDetector(BaseDetector):
         return self.bbox_head.get_bboxes_batched(*outs, img_meta, self.test_cfg, rescale)
 
     def simple_test_batch(self, img, img_meta, gt_bboxes=None, gt_labels=None, rescale=False):
-        """-> list over images of per-class ndarray lists (bbox2result)"""
+        """-> list over images of per-class ndarray lists (bbox2result, reference
+        core/bbox/transforms.py:148-166).  The whole batch comes back in ONE device-to-host copy
+        of fixed-size records (the reference copies detections and labels of every image
+        separately, two synchronisations per image)."""
+        if hasattr(self.bbox_head, 'get_bboxes_batched') and img.is_cuda:
+            from .dist import pack_detections, unpack_detections
+            dets, labels, _, num = self.simple_test_device(img, img_meta, rescale)
+            rec = pack_detections(dets, labels, num).cpu()          # the one host sync per batch
+            dets, labels, num = unpack_detections(rec, dets.shape[1])
+            dets, labels, num = dets.numpy(), labels.numpy(), num.tolist()
+            return [bbox2result(dets[b, :k], labels[b, :k], self.bbox_head.num_classes)
+                    for b, k in enumerate(num)]
         outs = self.forward_head(img)
         bbox_list = self.bbox_head.get_bboxes(*(outs + (gt_bboxes, gt_labels, img_meta,
                                                         self.test_cfg, rescale)))

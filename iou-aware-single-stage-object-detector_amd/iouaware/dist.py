@@ -87,7 +87,8 @@ def all_gather_detections(dets, labels, num, num_samples=None, force_collective=
     num_samples when given.  ONE collective per call: `all_gather_into_tensor` into a
     pre-allocated (W, B, M*6+1) buffer (RCCL on GPUs: a single ring / direct all-gather of
     W x B x 2.4 KB; gloo on CPU), falling back to the list form where a backend lacks it.
-    The rank interleave copies out of that buffer, so the result stays valid.
+    The result never aliases the persistent receive buffer (the rank interleave is a copy when
+    B > 1, an explicit clone otherwise), so it stays valid across later calls.
     force_collective: issue the collective even in a one-rank group (tests: RCCL on one GPU).
     """
     rank, world = get_dist_info()
@@ -103,6 +104,11 @@ def all_gather_detections(dets, labels, num, num_samples=None, force_collective=
             dist.all_gather(list(buf.unbind(0)), rec)
         # sample i of rank r is dataset index i*world + r (reference tools/test.py:95-99)
         allrec = buf.transpose(0, 1).reshape(world * rec.shape[0], rec.shape[1])
+        if allrec.data_ptr() == buf.data_ptr():
+            # B == 1 per rank (the reference's distributed testing, imgs_per_gpu=1) or a one-rank
+            # group: the "interleave" is a view of the persistent buffer, which the next call
+            # overwrites while the caller may still hold these detections
+            allrec = allrec.clone()
     if num_samples is not None:
         allrec = allrec[:num_samples]
     return unpack_detections(allrec, M)

@@ -48,7 +48,11 @@ def _stamp(module):
     and one running statistic per BatchNorm under `module`.  An optimizer step, a checkpoint
     load (in-place copies bump `_version`) or `.to(device / dtype)` (new storage) changes it."""
     out = []
-    for m in module.modules():
+    # a ResNet's own folded copies derive from its stem only (the blocks below are fused modules
+    # with their own stamps): do not walk ~160 modules per forward, and do not re-fold the frozen
+    # stem because a trainable stage took an optimizer step
+    scope = (module.conv1, module.norm1) if isinstance(module, ResNet) else (module,)
+    for m in (sub for top in scope for sub in top.modules()):
         if isinstance(m, torch.nn.Conv2d):
             out.append((m.weight.data_ptr(), m.weight._version))
             if m.bias is not None:

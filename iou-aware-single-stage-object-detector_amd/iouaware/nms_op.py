@@ -79,9 +79,11 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
                          % (n, ops._lib.IA_MAX_CANDIDATES))
     drop_last = max_num is None or max_num < 0
     if drop_last:
-        # reference quirk (bbox_nms.py:52-56): `shape[0] > -1` is always true, so the survivors
-        # are sorted by score and `inds[:-1]` drops the lowest one.  Emulated while the survivor
-        # count fits the library's per-image output buffer.
+        # reference quirk (bbox_nms.py:52-56): `shape[0] > -1` is always true, so ALL survivors
+        # are sorted by score (descending) and `inds[:-1]` drops the globally lowest one.
+        # Emulated while the survivor count fits the library's per-image output buffer: the
+        # kernel is asked for `cap` rows, which it returns unsorted (class-major) when fewer
+        # survive; the sort and the drop happen below.
         max_num = cap
     elif max_num > cap:
         raise ValueError('multiclass_nms: max_num=%d exceeds the per-image output capacity %d'
@@ -101,5 +103,8 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
         if k >= cap:
             raise ValueError('multiclass_nms(max_num=-1): %d or more survivors, beyond the '
                              'per-image output capacity; pass an explicit max_num' % cap)
-        k = max(k - 1, 0)
+        dets, labels = out[0][0, :k], out[1][0, :k].to(torch.long)
+        # stable: equal scores keep their concatenation order (class ascending, row ascending)
+        order = torch.sort(dets[:, 4], descending=True, stable=True)[1][:max(k - 1, 0)]
+        return dets[order], labels[order]
     return out[0][0, :k], out[1][0, :k].to(torch.long)

@@ -803,10 +803,12 @@ def anchor_targets(geom, gt_bboxes, gt_labels, pad_shapes, pos_iou_thr, neg_iou_
     if B <= _lib.IA_MAX_TARGET_BATCH:
         # gt tensors stay where the loader put them: their pointers and sizes ride in the kernel
         # arguments (no padded staging copy, no host-to-device transfer)
-        keep = [g_.to(torch.float32).contiguous() for g_ in gt_bboxes]
+        # (.to(dev, ...) is a no-op for tensors already there; a host or other-device tensor is
+        # copied over instead of handing its pointer to the kernel)
+        keep = [g_.to(dev, torch.float32).contiguous() for g_ in gt_bboxes]
         gp = (C.c_void_p * B)(*[g_.data_ptr() for g_ in keep])
         if gt_labels is not None:
-            keep_l = [l_.to(torch.int64).contiguous() for l_ in gt_labels]
+            keep_l = [l_.to(dev, torch.int64).contiguous() for l_ in gt_labels]
             lp = (C.c_void_p * B)(*[l_.data_ptr() for l_ in keep_l])
         else:
             lp = None
@@ -959,6 +961,12 @@ def _shared_base(r, i):
         return None
     ps = b.shape[1]
     if _pix_stride(r) != ps or _pix_stride(i) != ps:
+        return None
+    # the backward writes the gradient of reg | iou into one tensor shaped like `b` and zeroes
+    # only what lies BEHIND them: the slices must be channels [0, n_reg) and [n_reg, n_reg + n_iou)
+    n_reg = r.shape[1]
+    if r.storage_offset() != b.storage_offset() or \
+            i.storage_offset() != b.storage_offset() + n_reg or n_reg + i.shape[1] > ps:
         return None
     return b
 

@@ -203,13 +203,32 @@ def wino_conv_levels(xs, weight, bias=None, relu=False):
     return list(_WinoConvLevels.apply(weight, bias, relu, *xs))
 
 
+def _plain_3x3(conv):
+    """3x3 / stride 1 / pad 1 / dilation 1 / groups 1 nn.Conv2d -- what the Winograd route computes"""
+    return (type(conv) is torch.nn.Conv2d and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.padding_mode == 'zeros')
+
+
+def _library_loads():
+    from . import _lib
+    try:
+        _lib.lib()
+        return True
+    except Exception:                     # missing .so: the plain modules still train (MIOpen)
+        return False
+
+
 def usable(feats, head):
+    towers = list(head.cls_convs) + list(head.reg_convs)
     return (torch.is_grad_enabled() and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                                             for x in feats)
             and head.in_channels % 4 == 0 and head.feat_channels % 4 == 0
             and (head.num_anchors * head.cls_out_channels) % 4 == 0
-            and all(not m.with_norm and m.with_activatation
-                    for m in list(head.cls_convs) + list(head.reg_convs)))
+            and all(not m.with_norm and m.with_activatation and _plain_3x3(m.conv) for m in towers)
+            and all(_plain_3x3(c) for c in (head.retina_cls, head.retina_reg, head.retina_iou))
+            and _library_loads())
 
 
 def head_forward(head, feats):

@@ -392,6 +392,133 @@ def gen_losses():
 
 
 
+# ---------------------------------------------------------------- multiclass_nms, max_num = -1
+def gen_mnms_quirk():
+    """bbox_nms.py:52-56 with the default max_num=-1: `shape[0] > -1` always holds, so ALL
+    survivors are sorted by score (descending) and `inds[:-1]` drops the globally lowest one.
+    Three classes; the LAST class holds the highest scores, so dropping the tail of the class-major
+    concatenation instead would lose a top detection."""
+    from mmdet.core.post_processing.bbox_nms import multiclass_nms
+    rs = np.random.RandomState(17)
+    n = 300
+    xy = rs.uniform(0, 400, (n, 2))
+    boxes = np.concatenate([xy, xy + rs.uniform(8, 80, (n, 2))], 1).astype(np.float32)
+    sc = np.zeros((n, 4), np.float32)
+    sc[:, 1] = rs.uniform(0.0, 0.6, n)
+    sc[:, 2] = rs.uniform(0.0, 0.7, n)
+    sc[:, 3] = rs.uniform(0.4, 1.0, n)
+    assert np.unique(sc[:, 1:]).size == 3 * n                       # tie-free
+    out = dict(boxes=boxes, scores=sc, score_thr=np.float32(0.3), iou_thr=np.float32(0.5))
+    cfg = dict(type='nms', iou_thr=0.5)
+    for name, mx in (('m1', -1), ('k20', 20), ('all', 100000)):
+        b, l = multiclass_nms(torch.from_numpy(boxes), torch.from_numpy(sc), 0.3, cfg, mx)
+        out['bboxes_' + name] = b.numpy()
+        out['labels_' + name] = l.numpy()
+        print('mnms', name, b.shape, 'labels of the first 5', l[:5].tolist())
+    assert out['bboxes_m1'].shape[0] == out['bboxes_all'].shape[0] - 1
+    save('mnms_quirk', **out)
+
+
+# ---------------------------------------------------------------- get_bboxes, 4-vector scale_factor
+def gen_get_bboxes_vecscale():
+    """rescale=True with the 4-vector scale_factor of a non-keep-ratio resize
+    (mmdet/datasets/transforms.py:33-38; divided out at iou_aware_retina_head.py:554)"""
+    head = IoUawareRetinaHead(**HEAD_KW)
+    cfg = ref_shim.to_cfg(dict(nms_pre=300, min_bbox_size=0, score_thr=0.05,
+                               nms=dict(type='nms', iou_thr=0.5), max_per_img=100))
+    seed, B, ih, iw, ph, pw = 111, 2, 120, 157, 128, 160
+    cls, reg, iou = synth.head_outputs(seed, B, ph, pw, 'A')
+    sfs = [np.array([1.25, 1.6, 1.25, 1.6], np.float32),
+           np.array([0.8, 0.5, 0.8, 0.5], np.float32)]
+    metas = [synth.img_meta(ih, iw, ph, pw, sfs[0]), synth.img_meta(ih, iw, ph, pw, sfs[1])]
+    res = run_ref_get_bboxes(head, cls, reg, iou, metas, cfg, True)
+    out = dict(seed=seed, batch=B, img=np.array([ih, iw, ph, pw]), kind='A', nms_pre=300,
+               score_thr=np.float32(0.05), iou_thr=np.float32(0.5), max_per_img=100,
+               scale_factors=np.stack(sfs), rescale=1, checksum=synth.checksum(cls + reg + iou))
+    for b, r in enumerate(res):
+        for k in ('det_bboxes', 'det_labels', 'det_rows', 'topk_inds', 'keep_count', 'keep_rows',
+                  'mlvl_bboxes', 'mlvl_scores', 'topk_margin'):
+            out['%s_%d' % (k, b)] = r[k]
+        print('vecscale img', b, 'dets', r['det_bboxes'].shape, 'margins', r['topk_margin'])
+    save('get_bboxes_vecscale', **out)
+
+
+# ---------------------------------------------------------------- losses, mixed pad shapes (T1)
+def gen_losses_mixed_pad():
+    """Two images of DIFFERENT pad_shape in one batch tensor: the second image's valid_flags /
+    inside_flags are partly false (anchor_head.py:135-146, anchor_generator.py:72-84,
+    anchor_target.py:168-172,258-282 `unmap`), so its out-of-pad anchors get label 0 / weight 0."""
+    head = IoUawareRetinaHead(**HEAD_KW)
+    train_cfg = ref_shim.to_cfg(dict(
+        assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
+                      ignore_iof_thr=-1),
+        allowed_border=-1, pos_weight=-1, debug=False))
+    seed, B, ph, pw = 313, 2, 128, 160
+    shapes = [(120, 157, 128, 160), (90, 100, 96, 128)]        # img_h, img_w, pad_h, pad_w
+    cls, reg, iou = synth.head_outputs(seed, B, ph, pw, 'A')
+    gts, gls = [], []
+    for b, (ih, iw, _, _) in enumerate(shapes):
+        g, l = synth.train_targets(seed + 1 + b, 1, ih, iw)
+        gts.append(g[0])
+        gls.append(l[0])
+    metas = [synth.img_meta(*s, 1.0) for s in shapes]
+    out = dict(seed=seed, batch=B, tensor=np.array([ph, pw]), shapes=np.array(shapes), kind='A',
+               checksum=synth.checksum(cls + reg + iou))
+    for b in range(B):
+        out['gt_bboxes_%d' % b] = gts[b]
+        out['gt_labels_%d' % b] = gls[b]
+    captured = {}
+    orig_at = ref_head_mod.anchor_target
+    orig_ga = head.get_anchors
+
+    def at(*a, **k):
+        r = orig_at(*a, **k)
+        captured['t'] = r
+        return r
+
+    def ga(*a, **k):
+        r = orig_ga(*a, **k)
+        # anchor_target concatenates these lists in place (anchor_target.py:52-54): keep copies
+        captured['valid'] = [[f.clone() for f in fl] for fl in r[1]]
+        return r
+
+    ref_head_mod.anchor_target = at
+    head.get_anchors = ga
+    rs = np.random.RandomState(98)
+    tc = [torch.from_numpy(x).requires_grad_(True) for x in cls]
+    tr = [torch.from_numpy(x).requires_grad_(True) for x in reg]
+    ti = [torch.from_numpy(x).requires_grad_(True) for x in iou]
+    losses = head.loss(tc, tr, ti, [torch.from_numpy(g) for g in gts],
+                       [torch.from_numpy(g) for g in gls], metas, train_cfg)
+    ref_head_mod.anchor_target = orig_at
+    sum(sum(v) for v in losses.values()).backward()
+    for k, v in losses.items():
+        out[k] = np.array([float(x) for x in v], np.float64)
+    (labels, lw, bt, bw, npos, nneg, lvl_anchor) = captured['t']
+    out['num_total_pos'] = npos
+    out['num_total_neg'] = nneg
+    for l in range(5):
+        out['labels_%d' % l] = labels[l].numpy()
+        out['label_weights_%d' % l] = lw[l].numpy()
+        out['bbox_targets_%d' % l] = bt[l].numpy()
+        out['bbox_weights_%d' % l] = bw[l].numpy()
+        for b in range(B):
+            out['valid_%d_%d' % (b, l)] = captured['valid'][b][l].numpy()
+        for nm, tl in (('cls', tc), ('reg', tr), ('iou', ti)):
+            g = tl[l].grad.numpy().reshape(-1)
+            key = 'g_%s_%d' % (nm, l)
+            out[key + '_idx'] = rs.choice(g.size, min(g.size, 3000), replace=False).astype(np.int64)
+            out[key] = g[out[key + '_idx']]
+            out[key + '_sum'] = np.float64(g.astype(np.float64).sum())
+            out[key + '_abs'] = np.float64(np.abs(g.astype(np.float64)).sum())
+    inval = [int((captured['valid'][1][l] == 0).sum()) for l in range(5)]
+    print('mixed pad: losses', {k: out[k] for k in ('loss_cls', 'loss_bbox', 'losses_iou')},
+          'num_total_pos', npos, 'invalid anchors of image 1 per level', inval)
+    assert sum(inval) > 0 and all(int((captured['valid'][0][l] == 0).sum()) == 0 for l in range(5))
+    save('losses_mixed_pad', **out)
+
+
+
 # ---------------------------------------------------------------- IoU-balanced losses (8f.4)
 def gen_losses_balanced():
     """head.loss with loss_cls = IOUbalancedSigmoidFocalLoss(eta=1.5) and loss_bbox =
@@ -715,6 +842,7 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones']
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones', 'mnms_quirk', 'get_bboxes_vecscale',
+                             'losses_mixed_pad']
     for w in which:
         globals()['gen_' + w]()

@@ -5,13 +5,28 @@ import torch
 import synth
 
 
+def product_base_anchors(strides=synth.STRIDES, octave_base_scale=4, scales_per_octave=3,
+                         ratios=(0.5, 1.0, 2.0)):
+    """the base anchors the PRODUCT generates (iouaware/anchors.py, the generator behind
+    head.geometry) -- the HIP path must not be fed the checker's anchors"""
+    from iouaware.anchors import AnchorGenerator
+    scales = np.array([2 ** (i / scales_per_octave) for i in range(scales_per_octave)]) \
+        * octave_base_scale
+    return np.stack([AnchorGenerator(s, scales, list(ratios)).base_anchors.numpy()
+                     for s in strides])
+
+
 def geometry(pad_h, pad_w, nms_pre, means=(0, 0, 0, 0), stds=(1, 1, 1, 1)):
+    """-> (HIP geometry built from the product's anchor generator, the ORACLE's base anchors for
+    the checker side); the two generators must agree bit for bit"""
     import oracle
     from iouaware import ops
     sizes = synth.level_shapes(pad_h, pad_w)
-    base = oracle.head_base_anchors(synth.STRIDES)
+    base_oracle = oracle.head_base_anchors(synth.STRIDES)
+    base = product_base_anchors()
+    assert base.dtype == np.float32 and np.array_equal(base, base_oracle)
     return ops.HeadGeometry(sizes, synth.STRIDES, base, synth.C, nms_pre=nms_pre, means=means,
-                            stds=stds), base
+                            stds=stds), base_oracle
 
 
 def to_dev(arrs, dtype=torch.float32):

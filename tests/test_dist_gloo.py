@@ -73,6 +73,38 @@ def test_all_gather_detections_world2_gloo():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _alias_worker(rank, world, port, ret):
+    """B = 1 per rank, two calls: the first result must survive the second call (the
+    rank interleave of a (W, 1, rec) buffer is a view of the persistent receive buffer)"""
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from iouaware import dist as idist
+    idist.init_dist('pytorch', backend='gloo')
+    outs = []
+    for call in range(2):
+        d, l, n = _fake_dets(10 * call + rank)
+        outs.append(idist.all_gather_detections(torch.from_numpy(d[None]), torch.from_numpy(l[None]),
+                                                torch.tensor([n], dtype=torch.int32)))
+    ok = True
+    for call in range(2):
+        D, L, N = outs[call]
+        for r in range(world):
+            ed, el, ek = _fake_dets(10 * call + r)
+            ok &= bool(np.array_equal(D[r].numpy(), ed) and np.array_equal(L[r].numpy(), el)
+                       and int(N[r]) == ek)
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_result_does_not_alias_the_receive_buffer():
+    world, port = 2, _free_port()
+    ret = mp.get_context('spawn').Manager().dict()
+    mp.spawn(_alias_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_pack_unpack_roundtrip():
     sys.path.insert(0, PKG)
     from iouaware import dist as idist
@@ -173,6 +205,58 @@ def test_bench_timed_region_and_exchange_world2():
     mp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world)), dict(ret)
     assert ret[0][1] == ret[1][1]                  # every rank holds the same (maximum) time
+
+
+def _run_bench(argv, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher) must start 2 ranks -- the
+    reference's launcher takes the GPU count and spawns (tools/dist_test.sh:7-10).  --dry-run:
+    gloo backend, fake detections; the launcher, the group-size checks, timed_region and the
+    exchange are the code a real N-GPU run executes."""
+    rc, rec, err = _run_bench(['--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1'])
+    assert rc == 0, err[-2000:]
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['exchange_ok'] is True
+    assert rec['launched_by'].startswith('bench.py --gpus 2')
+    assert rec['steps'] == 3 and rec['warmup'] == 1
+
+
+def test_bench_under_the_drivers_launcher_and_flag_mismatch():
+    """the driver's form: torch.distributed.run ... bench.py --gpus N; a --gpus that disagrees
+    with the launcher's WORLD_SIZE is an error, not a silent single-rank run"""
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+            os.path.join(ROOT, 'bench.py'), '--dry-run', '--steps', '2', '--warmup', '1']
+    p = subprocess.run(base + ['--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    import json
+    rec = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert p.returncode == 0 and rec['n_gpus'] == 2 and rec['launched_by'] == 'external launcher'
+    base[base.index('--master-port') + 1] = str(_free_port())
+    p = subprocess.run(base + ['--gpus', '4'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert 'WORLD_SIZE=2' in p.stderr.decode() + p.stdout.decode()
+
+
+def test_bench_single_process_dry_run_unchanged():
+    rc, rec, err = _run_bench(['--dry-run', '--steps', '2', '--warmup', '1'])
+    assert rc == 0 and rec['n_gpus'] == 1 and rec['launched_by'] == 'single process', err[-500:]
 
 
 def _none_loss_worker(rank, world, port, ret):

@@ -125,7 +125,7 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
     return out
 
 
-@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C'])
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale'])
 def test_get_bboxes_vs_oracle_and_golden(ops, oracle_lib, golden_dir, name):
     f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
     ih, iw, ph, pw = [int(v) for v in f['img']]
@@ -133,7 +133,9 @@ def test_get_bboxes_vs_oracle_and_golden(ops, oracle_lib, golden_dir, name):
     cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
     assert synth.checksum(cls + reg + iou) == int(f['checksum'])
     geom, base = G.geometry(ph, pw, int(f['nms_pre']))
-    metas = [synth.img_meta(ih, iw, ph, pw, float(f['scale_factors'][b])) for b in range(B)]
+    # 'vecscale': the 4-vector scale_factor of a non-keep-ratio resize (transforms.py:33-38)
+    from test_oracle_golden import scale_factor_of
+    metas = [synth.img_meta(ih, iw, ph, pw, scale_factor_of(f, b)) for b in range(B)]
     res = check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas,
                                bool(f['rescale']), float(f['score_thr']), float(f['iou_thr']),
                                int(f['max_per_img']))
@@ -355,19 +357,24 @@ def test_channels_last_other_class_counts(ops, oracle_lib, Cn, dtype):
         assert G.same_bits(dets[b, :n].cpu().numpy(), o['det_bboxes'])
 
 
-def test_multiclass_nms_wrapper_max_num_minus_one_quirk(ops):
-    """bbox_nms.py:52-56 with the default max_num=-1: `shape[0] > -1` is always true, the
-    survivors are sorted by score and `inds[:-1]` drops the lowest one"""
+def test_multiclass_nms_wrapper_max_num_minus_one_quirk(ops, golden_dir):
+    """bbox_nms.py:52-56 with the default max_num=-1: `shape[0] > -1` is always true, ALL
+    survivors are sorted by score (descending) and `inds[:-1]` drops the globally lowest one.
+    Fixture: the reference's own multiclass_nms on 3 classes whose LAST class holds the highest
+    scores (tests/golden/mnms_quirk.npz) -- the class-major tail is a high-score box there."""
     from iouaware import nms_op
-    rs = np.random.RandomState(3)
-    n = 300
-    xy = rs.uniform(0, 400, (n, 2))
-    boxes = torch.from_numpy(np.concatenate([xy, xy + rs.uniform(8, 80, (n, 2))], 1).astype(np.float32)).cuda()
-    sc = rs.uniform(0, 1, (n, 4)).astype(np.float32)
-    sc[:, 0] = 0
-    scores = torch.from_numpy(sc).cuda()
-    cfg = dict(type='nms', iou_thr=0.5)
-    full_b, full_l = nms_op.multiclass_nms(boxes, scores, 0.3, cfg, 1024)
-    quirk_b, quirk_l = nms_op.multiclass_nms(boxes, scores, 0.3, cfg)          # max_num = -1
-    assert full_b.shape[0] > 10 and quirk_b.shape[0] == full_b.shape[0] - 1
-    assert torch.equal(quirk_b, full_b[:-1]) and torch.equal(quirk_l, full_l[:-1])
+    f = np.load(os.path.join(golden_dir, 'mnms_quirk.npz'))
+    boxes = torch.from_numpy(f['boxes']).cuda()
+    scores = torch.from_numpy(f['scores']).cuda()
+    cfg = dict(type='nms', iou_thr=float(f['iou_thr']))
+    thr = float(f['score_thr'])
+    for name, mx in (('m1', -1), ('k20', 20), ('all', 1024)):
+        b, l = nms_op.multiclass_nms(boxes, scores, thr, cfg, mx)
+        assert l.dtype == torch.long
+        assert np.array_equal(l.cpu().numpy(), f['labels_' + name]), name
+        assert np.array_equal(b.cpu().numpy(), f['bboxes_' + name]), name    # gathered, not computed
+    b, l = nms_op.multiclass_nms(boxes, scores, thr, cfg)                     # the default
+    assert np.array_equal(b.cpu().numpy(), f['bboxes_m1'])
+    # sorted by score, and the dropped one is the global minimum of the survivors
+    assert (np.diff(f['bboxes_m1'][:, 4]) <= 0).all()
+    assert f['bboxes_all'][:, 4].min() < f['bboxes_m1'][:, 4].min()

@@ -32,6 +32,56 @@ def test_device_targets_equal_reference(golden_dir):
         assert np.allclose(bt[l].cpu().numpy(), f['bbox_targets_%d' % l], rtol=1e-5, atol=1e-6)
 
 
+def test_device_targets_and_losses_mixed_pad_shapes_equal_reference(golden_dir):
+    """T1 pinned on the reference: images of different pad_shape in one batch (partly false
+    valid_flags / inside_flags, `unmap`): ia_anchor_targets and the whole head.loss (device
+    targets + all-levels loss kernels, both layouts) against tests/golden/losses_mixed_pad.npz"""
+    from iouaware import ops
+    from iouaware.head import IoUawareRetinaHead
+    from test_host_targets import HEAD_KW, TRAIN_CFG
+    f = np.load(os.path.join(golden_dir, 'losses_mixed_pad.npz'))
+    ph, pw = [int(v) for v in f['tensor']]
+    B = int(f['batch'])
+    shapes = [[int(v) for v in f['shapes'][b]] for b in range(B)]
+    geom, base = G.geometry(ph, pw, -1)
+    gts = [torch.from_numpy(f['gt_bboxes_%d' % b]).cuda() for b in range(B)]
+    gls = [torch.from_numpy(f['gt_labels_%d' % b]).cuda() for b in range(B)]
+    pads = [(s[2], s[3], 3) for s in shapes]
+    labels, lw, bt, bw, counts = ops.anchor_targets(geom, gts, gls, pads, 0.5, 0.4, 0.0, -1)
+    assert int(counts[:, 0].clamp(min=1).sum()) == int(f['num_total_pos'])
+    assert int(counts[:, 1].clamp(min=1).sum()) == int(f['num_total_neg'])
+    for l in range(5):
+        assert np.array_equal(labels[l].cpu().numpy(), f['labels_%d' % l])
+        assert np.array_equal(lw[l].cpu().numpy(), f['label_weights_%d' % l])
+        assert np.array_equal(bw[l].cpu().numpy(), f['bbox_weights_%d' % l])
+        assert np.allclose(bt[l].cpu().numpy(), f['bbox_targets_%d' % l], rtol=1e-5, atol=1e-6)
+        inval = torch.from_numpy(f['valid_1_%d' % l] == 0).cuda()
+        assert int(inval.sum()) > 0 and float(lw[l][1][inval].abs().sum()) == 0.0
+    # the loss dict and the gradients of the head outputs, as the reference's autograd gives them
+    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    assert synth.checksum(cls + reg + iou) == int(f['checksum'])
+    head = IoUawareRetinaHead(**HEAD_KW).cuda()
+    metas = [synth.img_meta(*s) for s in shapes]
+    for channels_last in (False, True):
+        c, r, i = [[t.contiguous(memory_format=torch.channels_last) if channels_last else t
+                    for t in G.to_dev(x)] for x in (cls, reg, iou)]
+        for t in c + r + i:
+            t.requires_grad_(True)
+        losses = head.loss(c, r, i, gts, gls, metas, TRAIN_CFG)
+        for k in ('loss_cls', 'loss_bbox', 'losses_iou'):
+            got = np.array([float(x) for x in losses[k]])
+            assert np.all(np.abs(got - f[k]) <= 1e-4 * np.maximum(np.abs(f[k]), 1e-6)), (k, got, f[k])
+        sum(sum(v) for v in losses.values()).backward()
+        for l in range(5):
+            for key, g in (('g_cls_%d' % l, c[l].grad), ('g_reg_%d' % l, r[l].grad),
+                           ('g_iou_%d' % l, i[l].grad)):
+                want = f[key].astype(np.float64)
+                got = g.contiguous().cpu().numpy().reshape(-1)[f[key + '_idx']].astype(np.float64)
+                assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), key
+                tot = float(g.double().sum())
+                assert abs(tot - float(f[key + '_sum'])) <= 2e-4 * max(float(f[key + '_abs']), 1e-30)
+
+
 @pytest.mark.parametrize('seed,pad', [(1, (800, 1344)), (2, (320, 416)), (3, (608, 1024))])
 def test_device_targets_equal_torch_path(seed, pad):
     """full-size and odd-size batches, padded images (valid flags), many gts"""

@@ -97,16 +97,22 @@ def test_nms_matches_real_reference_binary(oracle_lib):
         assert np.array_equal(oracle_lib.nms(dets, 0.5), ref)
 
 
+def scale_factor_of(f, b):
+    """python float (keep-ratio resize) or the fp32 4-vector of transforms.py:35-38"""
+    sf = f['scale_factors'][b]
+    return float(sf) if np.ndim(sf) == 0 else np.asarray(sf, np.float32)
+
+
 def run_oracle(oracle_lib, f, b, cls, reg, iou):
     ih, iw, ph, pw = [int(v) for v in f['img']]
     base = oracle_lib.head_base_anchors(synth.STRIDES)
     return oracle_lib.get_bboxes_single(
         [x[b] for x in cls], [x[b] for x in reg], [x[b] for x in iou], synth.STRIDES, base,
-        (ih, iw), float(f['scale_factors'][b]), bool(f['rescale']), int(f['nms_pre']),
+        (ih, iw), scale_factor_of(f, b), bool(f['rescale']), int(f['nms_pre']),
         float(f['score_thr']), float(f['iou_thr']), int(f['max_per_img']))
 
 
-@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C'])
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale'])
 def test_get_bboxes(oracle_lib, golden_dir, name):
     f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
     ih, iw, ph, pw = [int(v) for v in f['img']]
