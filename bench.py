@@ -123,6 +123,7 @@ class Stepper(object):
         self.pending, self.count = [], 0
         self.last = None
         self.nhwc = False
+        self.sel_ws = None
 
     @torch.no_grad()
     def step(self, timed=False):
@@ -153,10 +154,12 @@ class Stepper(object):
             stage = self.count % 2 == 1
             e0, e1 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             e0.record()
-            rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
+            if self.sel_ws is None:
+                self.sel_ws = ops.select_workspace(geom, cls[0].shape[0], cls[0].device)
+            rm = ops.decode_fuse_rowmax(geom, cls, reg, iou, self.sel_ws)
             if not stage:
                 e1.record()
-            idx = ops.select_topk(geom, rm)
+            idx = ops.select_topk(geom, rm, self.sel_ws)
             boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors,
                                                       True)
             if stage:

@@ -94,6 +94,18 @@ size_t ia_select_topk_workspace_bytes(const ia_head_geom *g, int batch);
 int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_t *cand_idx,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same two stages the way ia_get_bboxes chains them: the row-max kernel also leaves, inside
+ * the top-k workspace (ia_select_topk_workspace_bytes), the maxima of groups of 64 / 16 / 4
+ * consecutive scores of the large levels and the cleared candidate counters, which is where
+ * ia_select_topk_grouped starts (ia_select_topk derives them from `rowmax` with an extra pass).
+ * Both calls take the SAME workspace, back to back on one stream.                              */
+int ia_decode_fuse_rowmax_grouped(const ia_head_geom *g, const ia_level_ptrs *p, int batch,
+                                  int dtype, float *rowmax, void *select_workspace,
+                                  size_t workspace_bytes, void *stream);
+int ia_select_topk_grouped(const ia_head_geom *g, const float *rowmax, int batch,
+                           int32_t *cand_idx, void *select_workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* iou_aware_retina_head.py:545-558 + mmdet/core/bbox/transforms.py:44-78
  * (delta2bbox) + anchor_generator.py:53-70 (anchors regenerated, never read).
  * img_hw: (B,2) fp32 (img_shape h,w); scale_factor: (B,4) fp32.

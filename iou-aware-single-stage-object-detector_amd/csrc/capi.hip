@@ -111,6 +111,32 @@ int ia_select_topk(const ia_head_geom *g, const float *rowmax, int batch, int32_
     return ia::launch_select(t, rowmax, batch, cand_idx, workspace, (hipStream_t)stream);
 }
 
+int ia_decode_fuse_rowmax_grouped(const ia_head_geom *g, const ia_level_ptrs *p, int batch,
+                                  int dtype, float *rowmax, void *select_workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    ia::LevelTable t;
+    int rc = ia::make_level_table(g, t);
+    if (rc) return rc;
+    if (!p || batch < 1 || !select_workspace) return IA_E_ARG;
+    if (workspace_bytes < ia::select_workspace_bytes(t, batch)) return IA_E_WORKSPACE;
+    float *groupmax = ia::select_workspace_groupmax(t, batch, select_workspace);
+    return ia::launch_rowmax(t, *p, batch, dtype, rowmax, (hipStream_t)stream, groupmax);
+}
+
+int ia_select_topk_grouped(const ia_head_geom *g, const float *rowmax, int batch,
+                           int32_t *cand_idx, void *select_workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    ia::LevelTable t;
+    int rc = ia::make_level_table(g, t);
+    if (rc) return rc;
+    if (batch < 1 || !select_workspace) return IA_E_ARG;
+    if (workspace_bytes < ia::select_workspace_bytes(t, batch)) return IA_E_WORKSPACE;
+    return ia::launch_select(t, rowmax, batch, cand_idx, select_workspace, (hipStream_t)stream,
+                             true);
+}
+
 int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                      const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
                      int rescale, float *boxes, float *scores_t, float *best_score, void *stream)
@@ -284,8 +310,10 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
     ia::make_level_table(g, t);
     ia::BaseAnchors ba;
     ia::base_from_geom(g, ba);
-    if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s))) return rc;
-    if ((rc = ia::launch_select(t, rowmax, batch, cand, ws + w.off[8], s))) return rc;
+    // the row-max kernel also leaves the group maxima the top-k's filter starts from
+    float *groupmax = ia::select_workspace_groupmax(t, batch, ws + w.off[8]);
+    if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s, groupmax))) return rc;
+    if ((rc = ia::launch_select(t, rowmax, batch, cand, ws + w.off[8], s, true))) return rc;
     if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
                                 scale_factor, rescale, boxes, scores_t, best, w.Rs, s)))
         return rc;

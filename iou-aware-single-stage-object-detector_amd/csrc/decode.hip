@@ -34,7 +34,21 @@ struct RowmaxArgs {
     int32_t blk_off[IA_MAX_LEVELS + 1];   // prefix of tiles_l * A, levels in REVERSE order
     int32_t blocks_per_img;
     int32_t anchors_per_img;
+    // first step of the top-k (select.hip): maxima of groups of consecutive stored scores;
+    // groupmax == nullptr: not wanted
+    SelPlan plan;
+    float *groupmax;
 };
+
+// max over `lanes` (a power of two) neighbouring lanes, valid in every lane of the group
+__device__ __forceinline__ float lanes_max(float v, int lanes)
+{
+    for (int off = 1; off < lanes; off <<= 1) {
+        const float o = __shfl_xor(v, off);
+        v = (v < o) ? o : v;
+    }
+    return v;
+}
 
 // PPL positions per lane: one 16-byte load per class plane.  The logits are read
 // exactly once, so the loads are non-temporal (no L2 / Infinity-Cache allocation):
@@ -129,9 +143,45 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
 #pragma unroll
         for (int j = 0; j < PPL; ++j) il[j] = load_f32<T>(iou + pc[j]);
     }
+    float sc[PPL];
 #pragma unroll
-    for (int j = 0; j < PPL; ++j)
-        if (pos[j] < HW) out[pos[j]] = sqrt_sigmoidf_(m[j]) * sqrt_sigmoidf_(il[j]);
+    for (int j = 0; j < PPL; ++j) {
+        sc[j] = sqrt_sigmoidf_(m[j]) * sqrt_sigmoidf_(il[j]);
+        if (pos[j] < HW) out[pos[j]] = sc[j];
+        else sc[j] = 0.0f;                                  // scores are >= 0
+    }
+    if (a.groupmax) {
+        const int g = a.plan.grp[l];
+        if (g) {
+            // groups of g consecutive positions of this (image, anchor) plane
+            const int gpp = (HW + g - 1) / g;
+            float *gm = a.groupmax + a.plan.goff[l] + ((size_t)b * A + an) * gpp;
+            if (HW % PPL == 0) {                            // lane = PPL consecutive positions
+                if (g >= PPL) {
+                    float v = sc[0];
+#pragma unroll
+                    for (int j = 1; j < PPL; ++j) v = (v < sc[j]) ? sc[j] : v;
+                    const int lanes = g / PPL;
+                    v = lanes_max(v, lanes);
+                    if ((lane & (lanes - 1)) == 0 && pos[0] < HW) gm[pos[0] / g] = v;
+                } else {                                    // g = 4, PPL = 8: two groups per lane
+#pragma unroll
+                    for (int h = 0; h < PPL; h += 4) {
+                        float v = sc[h];
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) v = (v < sc[h + j]) ? sc[h + j] : v;
+                        if (pos[h] < HW) gm[pos[h] / g] = v;
+                    }
+                }
+            } else {                                        // lane = positions p0 + lane + 64 j
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    const float v = lanes_max(sc[j], g);
+                    if ((lane & (g - 1)) == 0 && pos[j] < HW) gm[pos[j] / g] = v;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -148,6 +198,8 @@ struct RowmaxNhwcArgs {
     float *rowmax;
     int32_t blk_off[IA_MAX_LEVELS + 1];   // prefix of ceil(B * N_l / 64), levels in REVERSE order
     int32_t batch, anchors_per_img;
+    SelPlan plan;                         // see RowmaxArgs
+    float *groupmax;
 };
 
 constexpr int kMaxVpr = 32;              // 16-byte vectors per row: C * sizeof(T) <= 512 bytes
@@ -193,25 +245,40 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
         for (int k = 0; k < vpr; ++k) body(k);
     }
     __syncthreads();
+    float score = 0.0f;                                     // scores are >= 0
     if (lane < nrow) {
         const float *sr = s_m + lane * (vpr + 1);
         float m = sr[0];
         for (int c4 = 1; c4 < vpr; ++c4) m = (m < sr[c4]) ? sr[c4] : m;
         const int b = (int)(g / n_l);
         const int i = (int)(g - (int64_t)b * n_l);
-        a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] =
-            sqrt_sigmoidf_(m) * sqrt_sigmoidf_(il);
+        score = sqrt_sigmoidf_(m) * sqrt_sigmoidf_(il);
+        a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] = score;
+    }
+    if (a.groupmax) {
+        // maxima of groups of grp consecutive rows of this level's flat (B * N_l) row space;
+        // r0 is a multiple of 64, so the groups are lane-aligned (a group that straddles two
+        // images is written like any other and left out by the reader)
+        const int grp = a.plan.grp[l];
+        if (grp) {
+            const float v = lanes_max(score, grp);
+            if ((lane & (grp - 1)) == 0 && lane < nrow)
+                a.groupmax[a.plan.goff[l] + (r0 + lane) / grp] = v;
+        }
     }
 }
 
 static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
-                              float *rowmax, hipStream_t s)
+                              float *rowmax, hipStream_t s, float *groupmax)
 {
     const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
     if (t.C % ppl != 0 || t.C / ppl > kMaxVpr) return IA_E_ARG;
     RowmaxNhwcArgs a;
     a.t = t; a.p = p; a.rowmax = rowmax; a.batch = batch;
     a.anchors_per_img = t.anchor_off[t.num_levels];
+    a.groupmax = groupmax;
+    int prc = make_sel_plan(t, batch, a.plan);
+    if (prc) return prc;
     a.blk_off[0] = 0;
     for (int rl = 0; rl < IA_MAX_LEVELS; ++rl) {
         const int l = t.num_levels - 1 - rl;
@@ -236,14 +303,18 @@ static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int b
 }
 
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
-                  hipStream_t s)
+                  hipStream_t s, float *groupmax)
 {
     if (batch < 1 || !rowmax) return IA_E_ARG;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
-    if (t.layout == IA_LAYOUT_NHWC) return launch_rowmax_nhwc(t, p, batch, dtype, rowmax, s);
+    if (t.layout == IA_LAYOUT_NHWC)
+        return launch_rowmax_nhwc(t, p, batch, dtype, rowmax, s, groupmax);
     const int tile = 64 * (dtype == IA_F32 ? Lane<float>::PPL : Lane<uint16_t>::PPL);
     RowmaxArgs a;
     a.t = t; a.p = p; a.rowmax = rowmax;
+    a.groupmax = groupmax;
+    int prc = make_sel_plan(t, batch, a.plan);
+    if (prc) return prc;
     a.blk_off[0] = 0;
     for (int rl = 0; rl < IA_MAX_LEVELS; ++rl) {
         const int l = t.num_levels - 1 - rl;

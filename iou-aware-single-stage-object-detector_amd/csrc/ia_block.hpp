@@ -6,6 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef IA_BLOCK_PROF
+#define IA_BLOCK_PROF(i) do { } while (0)      // phase timestamps of tools/ubench/select_bench.hip
+#endif
+
 namespace ia {
 
 constexpr int kWave = 64;
@@ -69,15 +73,21 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
 
 struct TopkScratch {
     uint32_t hist[2048];
-    uint32_t misc[8];   // 0: digit, 1: count above, 2: count in digit, 3: collect counter
+    uint32_t misc[8];   // 0: digit, 1: count above, 2: count in digit, 3: collect counter, 4: tie cut
 };
+
+constexpr uint32_t kTieShortcut = 512;   // ties resolved by rank counting instead of radix passes
 
 // Select the k largest of n UNIQUE 64-bit keys key(i), i in [0,n), and leave
 // them sorted descending in sel[0..k).  sel must hold next_pow2(k) entries.
 // 1 <= k <= n.  Whole workgroup participates (blockDim.x*blockDim.y threads,
 // a multiple of 64, >= 64).  MSB-first radix select with 11/11/10-bit digits;
 // stops as soon as the digit bin equals the remaining need, so tie-free score
-// keys never touch the low (index) half.
+// keys never touch the low (index) half.  When the high words (scores) tie across the cut
+// and at most kTieShortcut keys share the threshold score, the cut inside the tie group is
+// found by rank counting in LDS (one compaction pass + n_tie broadcast reads per thread)
+// instead of three more radix passes over all n keys: random-init networks put a handful of
+// equal scores on every cut, which used to double the kernel's time.
 template <class KeyFn>
 __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &sc, uint64_t *sel)
 {
@@ -86,6 +96,8 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
     uint64_t prefix = 0;
     int bits_done = 0;
     uint32_t need = k;
+    uint64_t cut = 0;                 // final answer: the selected keys are exactly those >= cut
+    bool have_cut = false;
     const int widths[6] = {11, 11, 10, 11, 11, 10};
     for (int pass = 0; pass < 6; ++pass) {
         const int wb = widths[pass];
@@ -93,7 +105,7 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
         const int shift = 64 - bits_done - wb;
         for (uint32_t i = tid; i < nbins; i += nt) sc.hist[i] = 0;
         __syncthreads();
-        // U keys per thread are fetched before any of them is binned: the key functor is a
+        // U keys per thread are fetched before any of them is binned: the key functor may be a
         // global load, and one load per ballot round would leave the pass latency-bound
         constexpr int U = 8;
         for (uint32_t base = 0; base < n; base += nt * U) {
@@ -145,14 +157,58 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
         prefix = (prefix << wb) | d;
         bits_done += wb;
         __syncthreads();
+        IA_BLOCK_PROF(2 + pass);
         if (in_d == need) break;
+        if (bits_done == 32 && in_d <= kTieShortcut) {
+            // in_d keys share the threshold's high word, `need` of them (the largest low words)
+            // are wanted: compact their low words into the (now free) histogram array and let
+            // every tie count how many ties lie above it
+            if (tid == 0) sc.misc[3] = 0;
+            __syncthreads();
+            for (uint32_t base = 0; base < n; base += nt * U) {
+                uint64_t xs[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t i = base + u * nt + tid;
+                    xs[u] = (i < n) ? key(i) : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t i = base + u * nt + tid;
+                    if (base + u * nt >= n) break;         // uniform
+                    const bool tie = (i < n) && ((xs[u] >> 32) == prefix);
+                    const uint64_t mt = __ballot(tie);
+                    if (mt) {
+                        uint32_t b0 = 0;
+                        const int leader = __builtin_ctzll(mt);
+                        if (lane_id() == leader)
+                            b0 = atomicAdd(&sc.misc[3], (uint32_t)__builtin_popcountll(mt));
+                        b0 = (uint32_t)__shfl((int)b0, leader);
+                        if (tie) sc.hist[b0 + lane_prefix_popc(mt)] = (uint32_t)xs[u];
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j < in_d; j += nt) {
+                const uint32_t lo = sc.hist[j];
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < in_d; ++q) rank += (sc.hist[q] > lo) ? 1u : 0u;
+                if (rank == need - 1) sc.misc[4] = lo;     // unique keys: exactly one writer
+            }
+            __syncthreads();
+            cut = (prefix << 32) | (uint64_t)sc.misc[4];
+            have_cut = true;
+            __syncthreads();
+            IA_BLOCK_PROF(8);
+            break;
+        }
     }
-    // collect everything whose top `bits_done` bits are >= prefix: exactly k keys
+    if (!have_cut) cut = (bits_done >= 64) ? prefix : (prefix << (64 - bits_done));
+    // collect everything >= cut: exactly k keys
     if (tid == 0) sc.misc[3] = 0;
     const uint32_t P = next_pow2(k);
     for (uint32_t i = tid; i < P; i += nt) sel[i] = 0;
     __syncthreads();
-    const int rs = 64 - bits_done;
     constexpr int U2 = 8;
     for (uint32_t base = 0; base < n; base += nt * U2) {
         uint64_t xs[U2];
@@ -166,7 +222,7 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
             const uint32_t i = base + u * nt + tid;
             if (base + u * nt >= n) break;                 // uniform
             const uint64_t x = xs[u];
-            bool take = (i < n) && ((rs == 0 ? x : (x >> rs)) >= prefix);
+            bool take = (i < n) && (x >= cut);
             uint64_t m = __ballot(take);
             if (m) {
                 uint32_t b0 = 0;
@@ -181,7 +237,9 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
         }
     }
     __syncthreads();
+    IA_BLOCK_PROF(9);
     bitonic_sort_desc(sel, P);
+    IA_BLOCK_PROF(10);
 }
 
 }  // namespace ia

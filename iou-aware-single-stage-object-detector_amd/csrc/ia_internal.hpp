@@ -43,12 +43,73 @@ inline int make_level_table(const ia_head_geom *g, LevelTable &t)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-level top-k plan shared by the row-max kernels (which emit group maxima) and select.hip.
+//
+// Levels with more than kSelDenseMax anchors are FILTERED before the exact selection: the anchors
+// of a segment (image, level) are partitioned into groups of g = 64 / 16 / 4 consecutive stored
+// scores; with v = the k-th largest group maximum, k DISTINCT scores are >= v, so the segment's
+// k-th largest score T is >= v and every top-k member is >= v: everything below v is dropped
+// without looking at it again (for independent scores about 1.25 k candidates survive).  Any
+// subset of the groups gives a valid (smaller) bound, so groups that straddle two images are
+// simply left out.  Smaller levels go to the exact selection whole.
+constexpr int kSelDenseMax = 12288;     // also the candidates the final kernel stages in LDS
+constexpr int kSelChunk = 4096;         // scores per filter workgroup
+
+struct SelPlan {
+    int32_t grp[IA_MAX_LEVELS];          // group size (0: the level is not filtered)
+    int32_t goff[IA_MAX_LEVELS + 1];     // prefix of the per-level group-maximum arrays (floats)
+    int32_t chunk_off[IA_MAX_LEVELS + 1];// prefix of ceil(N_l / kSelChunk) over filtered levels
+};
+
+// group arrays: channels-last heads: groups of g consecutive rows of the flat (B * N_l) row space
+// of a level (row = b * N_l + reference anchor index); NCHW heads: per (image, anchor) plane,
+// groups of g consecutive positions (the row-max array is stored anchor-major there)
+inline int64_t sel_group_count(const LevelTable &t, int l, int g, int batch)
+{
+    const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
+    if (t.layout == IA_LAYOUT_NHWC) return ((int64_t)batch * n + g - 1) / g;
+    const int64_t hw = (int64_t)t.H[l] * t.W[l];
+    return (int64_t)batch * t.A * ((hw + g - 1) / g);
+}
+
+inline int make_sel_plan(const LevelTable &t, int batch, SelPlan &p)
+{
+    p.goff[0] = 0; p.chunk_off[0] = 0;
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+        int g = 0, chunks = 0;
+        int64_t groups = 0;
+        if (l < t.num_levels) {
+            const int n = t.anchor_off[l + 1] - t.anchor_off[l];
+            const int k = t.cand_off[l + 1] - t.cand_off[l];
+            if (k < n && n > kSelDenseMax) {
+                // the coarsest grouping that still leaves about 2k groups per segment
+                g = 4;
+                for (int c : {64, 16}) if ((int64_t)n / c >= 2 * (int64_t)k + 2) { g = c; break; }
+                groups = sel_group_count(t, l, g, batch);
+                chunks = (n + kSelChunk - 1) / kSelChunk;
+            }
+        }
+        if (p.goff[l] + groups > 2147483647LL) return IA_E_ARG;
+        p.grp[l] = g;
+        p.goff[l + 1] = p.goff[l] + (int32_t)groups;
+        p.chunk_off[l + 1] = p.chunk_off[l] + chunks;
+    }
+    return 0;
+}
+
 // stage launchers (defined in the .hip files)
+// groupmax: when given, the row-max kernel also writes the group maxima of make_sel_plan's
+// filtered levels -- the first step of launch_select, folded into the streaming kernel
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
-                  hipStream_t s);
+                  hipStream_t s, float *groupmax = nullptr);
 size_t select_workspace_bytes(const LevelTable &t, int batch);
+// where launch_rowmax has to put the group maxima inside the select workspace
+float *select_workspace_groupmax(const LevelTable &t, int batch, void *workspace);
+// have_groups: the row-max kernel already filled the workspace's group maxima; otherwise an
+// extra pass over the row-max array derives them first
 int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
-                  void *workspace, hipStream_t s);
+                  void *workspace, hipStream_t s, bool have_groups = false);
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,

@@ -5,67 +5,79 @@
 // is implementation defined, so the canonical order here is (score
 // descending, anchor index ascending) -- identical to the oracle.
 //
-// Exact selection by threshold.  The k-th largest 32-bit score key T of a segment is found with
-// three chip-wide histogram passes over the (L2-resident, 806 KB per image) row-max array --
-// digits of 11 / 11 / 10 bits, every workgroup bins 4096 scores in LDS and adds its non-empty
-// bins to the segment's global histogram; the pass for digit d+1 only looks at the scores that
-// share the threshold's digits 0..d, which every workgroup re-derives from the previous
-// histogram.  A fourth pass collects the keys above T (they are selected whatever their order)
-// and the indices of the scores equal to T; one workgroup per segment then takes the lowest
-// anchor indices among the ties, sorts the k 64-bit keys (score desc, index asc) in LDS and
-// writes the candidate list.
+// Two launches behind the row-max kernel (before: three chip-wide histogram passes + a collect
+// pass + a one-workgroup sort, 5 launches and 72-90 us at batch 8):
 //
-//   k_sel_hist<0,1,2>   3 launches, ~1600 workgroups each at batch 8
-//   k_sel_collect       1 launch
-//   k_sel_final         1 workgroup per (image, level)
+//   k_sel_filter   large levels (N_l > kSelDenseMax).  The row-max kernel leaves, next to the
+//                  scores, the maximum of every group of g = 64 / 16 / 4 consecutive stored scores
+//                  (ia_internal.hpp, SelPlan).  With v <= the k-th largest group maximum of a
+//                  segment, k distinct scores are >= v, hence the k-th largest score T >= v and
+//                  every member of the top-k is >= v.  Each workgroup derives v from <= 4096 group
+//                  maxima -- ONE histogram pass over 2048 linear bins between their minimum and
+//                  maximum, v = the lower edge of the bin where the count from the top reaches k
+//                  -- and keeps the scores >= v of its 4096-score chunk as 64-bit keys
+//                  `ordered(score) << 32 | ~index` in the chunk's own slice of the candidate list
+//                  (no global atomics, nothing to clear).  Independent scores leave about 1.3 k
+//                  candidates of 151 200; the bound is valid for ANY input (all scores equal:
+//                  every score is a candidate and the final kernel takes its general path).
+//   k_sel_final    one workgroup per segment: the candidates (or the whole level when it is
+//                  small) are staged in LDS as unique 64-bit keys; one histogram pass over linear
+//                  bins between the smallest and largest staged score finds the bin holding the
+//                  cut; the keys above it are selected outright, the few inside it are ranked
+//                  against each other; bitonic sort with the short strides in registers
+//                  (ia_block.hpp) -> canonical order.  Inputs the shortcut does not fit (more than
+//                  1024 keys in the cut's bin -- heavy ties -- or more candidates than the LDS
+//                  stage holds) take the exact MSB-first radix select of ia_block.hpp.
 //
-// MI355X, batch 8, 800x1344 (rocprofv3, random-init-like near-tied scores and tie-free scores
-// alike): 9.7 + 9.1 + 8.8 + 10.8 + 15.6 = 54 us for the five launches (plus one memset) where
-// the earlier two-round radix select (one 1024-thread workgroup per ~9k-score part keeping its
-// own top-k, then a merge workgroup per segment: 55 + 53 us) spent its time in the barrier
-// chains of 176 workgroups.  Levels with N_l <= nms_pre keep their natural order (the reference
-// skips topk there, :537).
+// Levels with N_l <= nms_pre keep their natural order (the reference skips topk there, :537).
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
+
+// phase timestamps for tools/ubench/select_bench.hip (compiled out of the library)
+#ifdef IA_SEL_PROFILE
+namespace ia { __device__ unsigned long long g_sel_prof[2][IA_MAX_LEVELS][24]; }
+#define SEL_PROF(kern, lvl, i)                                                        \
+    do { if (blockIdx.y == 0 && threadIdx.x == 0) ia::g_sel_prof[kern][lvl][i] = wall_clock64(); } while (0)
+#define IA_BLOCK_PROF(i) SEL_PROF(1, blockIdx.x, i)
+#else
+#define SEL_PROF(kern, lvl, i) do { } while (0)
+#endif
 #include "ia_block.hpp"
 
 namespace ia {
 
-constexpr int kChunk = 4096;               // scores per histogram workgroup
-constexpr int kHistThreads = 256;
-constexpr int kBins = 2048;                // 11-bit digits (the last digit has 10 bits)
+constexpr int kFilterThreads = 256;
+constexpr int kBins = 2048;
 constexpr int kFinalThreads = 1024;
-constexpr int kCntStride = 64;             // the two counters of a segment own a 256-byte line pair
+constexpr int kMaxGroups = 4096;           // group maxima a filter workgroup looks at
+constexpr int kGroupsPerThread = kMaxGroups / kFilterThreads;
+constexpr int kMaxSegChunks = 1024;        // filter chunks per segment (N_l <= 4 M anchors)
 
 struct SelArgs {
     LevelTable t;
+    SelPlan plan;
     const float *rowmax;
+    const float *groupmax;
     int32_t *cand_idx;
-    uint32_t *hist;                        // (B, L, 3, kBins)
-    uint32_t *counters;                    // (B, L, kCntStride): [0] keys above the threshold, [1] ties
-    uint64_t *sure;                        // (B, R): keys above the threshold, unordered
-    uint32_t *ties;                        // (B, N): anchor indices of scores equal to it
-    int32_t chunk_off[IA_MAX_LEVELS + 1];  // prefix of ceil(N_l / kChunk) over selecting levels
-    int32_t anchors_per_img, cands_per_img;
+    uint32_t *chunk_count;                 // (B, chunks): candidates each filter workgroup kept
+    uint64_t *cand;                        // (B, N): candidate keys; chunk c of segment (b, l) owns
+                                           // [b * N + anchor_off[l] + c * kSelChunk, + kSelChunk)
+    int32_t batch, anchors_per_img, cands_per_img, lds_cap, total_chunks;
 };
 
-__device__ __forceinline__ int digit_of(uint32_t key, int level)
-{
-    return level == 0 ? (int)(key >> 21) : (level == 1 ? (int)((key >> 10) & 0x7ffu) : (int)(key & 0x3ffu));
-}
-
-// Threshold digit of one level from its histogram: the bin d (from the top) where the running
-// count reaches `need`.  Whole workgroup (256 threads); returns (d, count above d) to everyone.
-__device__ __forceinline__ void find_digit(const uint32_t *hist, int nbins, uint32_t need,
-                                           uint32_t *lds /* >= 260 */, int &d, uint32_t &above)
+// The bin d (from the top) where the running count of a 2048-bin histogram reaches `need`, by a
+// 256-thread workgroup; returns (d, count above d, count in d) to everyone.
+__device__ __forceinline__ void find_bin_256(const uint32_t *hist, uint32_t need,
+                                             uint32_t *lds /* >= 8 */, int &d, uint32_t &above,
+                                             uint32_t &in_d)
 {
     const int tid = threadIdx.x;
-    const int per = nbins / kHistThreads;          // 8 or 4 bins per thread, highest bins first
-    const int hi = nbins - per * tid;
-    uint32_t c[8];
+    constexpr int per = kBins / kFilterThreads;    // 8 bins per thread, highest bins first
+    const int hi = kBins - per * tid;
+    uint32_t c[per];
     uint32_t s = 0;
+#pragma unroll
     for (int j = 0; j < per; ++j) { c[j] = hist[hi - 1 - j]; s += c[j]; }
-    // inclusive scan over the threads (tid 0 owns the top bins)
     uint32_t incl = s;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -80,271 +92,451 @@ __device__ __forceinline__ void find_digit(const uint32_t *hist, int nbins, uint
     incl += base;
     const uint32_t excl = incl - s;
     if (excl < need && incl >= need) {             // exactly one thread
-        uint32_t a = excl;
+        uint32_t a = excl, cc = c[0];
         int dd = hi - 1;
+#pragma unroll
         for (int j = 0; j < per; ++j) {
-            if (a + c[j] >= need) { dd = hi - 1 - j; break; }
+            if (a + c[j] >= need) { dd = hi - 1 - j; cc = c[j]; break; }
             a += c[j];
         }
-        lds[4] = (uint32_t)dd; lds[5] = a;
+        lds[4] = (uint32_t)dd; lds[5] = a; lds[6] = cc;
     }
     __syncthreads();
-    d = (int)lds[4]; above = lds[5];
-    __syncthreads();
+    d = (int)lds[4]; above = lds[5]; in_d = lds[6];
 }
 
-struct SegRef { int l, b; uint32_t n, k, beg, cnt; const float *src; bool natural; uint32_t HW, A; };
+// shift that maps [0, range] onto at most kBins linear bins
+__device__ __forceinline__ int bin_shift(uint32_t range)
+{
+    const int bits = 32 - __builtin_clz(range | 1u);
+    return bits > 11 ? bits - 11 : 0;
+}
+
+struct SegRef { int l, b; uint32_t n, k, beg, cnt, chunk; const float *src; bool natural; uint32_t HW, A; };
 
 __device__ __forceinline__ SegRef locate_chunk(const SelArgs &a)
 {
     SegRef r;
     r.b = blockIdx.y;
     int l = 0;
-    while ((int)blockIdx.x >= a.chunk_off[l + 1]) ++l;
+    while ((int)blockIdx.x >= a.plan.chunk_off[l + 1]) ++l;
     r.l = l;
     r.n = (uint32_t)(a.t.anchor_off[l + 1] - a.t.anchor_off[l]);
     r.k = (uint32_t)(a.t.cand_off[l + 1] - a.t.cand_off[l]);
-    r.beg = (uint32_t)(blockIdx.x - a.chunk_off[l]) * kChunk;
-    r.cnt = (r.n - r.beg < (uint32_t)kChunk) ? (r.n - r.beg) : (uint32_t)kChunk;
+    r.chunk = (uint32_t)(blockIdx.x - a.plan.chunk_off[l]);
+    r.beg = r.chunk * kSelChunk;
+    r.cnt = (r.n - r.beg < (uint32_t)kSelChunk) ? (r.n - r.beg) : (uint32_t)kSelChunk;
     r.src = a.rowmax + (size_t)r.b * a.anchors_per_img + a.t.anchor_off[l];
     r.natural = a.t.layout == IA_LAYOUT_NHWC;
     r.HW = (uint32_t)(a.t.H[l] * a.t.W[l]); r.A = (uint32_t)a.t.A;
     return r;
 }
 
-// the thresholds of the levels below `upto` (re-derived by every workgroup from the global
-// histograms of the earlier launches): prefix = the digits found so far, need = what is still
-// missing among the scores that share them
-__device__ __forceinline__ void thresholds(const SelArgs &a, const SegRef &r, int upto, uint32_t *lds,
-                                           uint32_t &prefix, uint32_t &need)
+// the groups that lie completely inside segment (b, l): [first, first + count) of the level's array
+__device__ __forceinline__ void segment_groups(const LevelTable &t, int l, int b, int g,
+                                               int64_t &first, int64_t &count)
 {
-    const uint32_t *h = a.hist + ((size_t)r.b * a.t.num_levels + r.l) * 3 * kBins;
-    prefix = 0; need = r.k;
-    for (int lev = 0; lev < upto; ++lev) {
-        int d; uint32_t above;
-        find_digit(h + lev * kBins, lev == 2 ? 1024 : kBins, need, lds, d, above);
-        need -= above;
-        prefix = (lev == 2) ? ((prefix << 10) | (uint32_t)d) : ((prefix << 11) | (uint32_t)d);
+    const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
+    if (t.layout == IA_LAYOUT_NHWC) {
+        first = ((int64_t)b * n + g - 1) / g;
+        const int64_t end = ((int64_t)(b + 1) * n) / g;
+        count = end > first ? end - first : 0;
+    } else {
+        const int64_t gpp = ((int64_t)t.H[l] * t.W[l] + g - 1) / g;
+        first = (int64_t)b * t.A * gpp;
+        count = (int64_t)t.A * gpp;
     }
 }
 
-template <int LEVEL>
-__global__ void __launch_bounds__(kHistThreads) k_sel_hist(SelArgs a)
+// Fallback producer of the group maxima (the stage-wise C-ABI, where the row-max array comes from
+// the caller): one thread per group over the stored scores.
+__global__ void __launch_bounds__(256) k_sel_groupmax(SelArgs a, float *groupmax)
+{
+    const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int l = 0;
+    while (l < a.t.num_levels && gid0 >= a.plan.goff[l + 1]) ++l;
+    if (l >= a.t.num_levels) return;
+    const int g = a.plan.grp[l];
+    const int64_t gid = gid0 - a.plan.goff[l];
+    const int64_t n = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
+    float m = 0.0f;                                 // scores are >= 0
+    if (a.t.layout == IA_LAYOUT_NHWC) {
+        for (int j = 0; j < g; ++j) {
+            const int64_t r = gid * g + j;
+            if (r >= (int64_t)a.batch * n) break;
+            const int64_t b = r / n, i = r - b * n;
+            const float v = a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i];
+            m = (m < v) ? v : m;
+        }
+    } else {
+        const int64_t hw = (int64_t)a.t.H[l] * a.t.W[l];
+        const int64_t gpp = (hw + g - 1) / g;
+        const int64_t plane = gid / gpp, q = gid - plane * gpp;      // plane = b * A + an
+        const int64_t b = plane / a.t.A, an = plane - b * a.t.A;
+        const float *src = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l] + an * hw;
+        for (int j = 0; j < g; ++j) {
+            const int64_t pos = q * g + j;
+            if (pos >= hw) break;
+            m = (m < src[pos]) ? src[pos] : m;
+        }
+    }
+    groupmax[gid0] = m;
+}
+
+__global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
 {
     __shared__ uint32_t s_hist[kBins];
-    __shared__ uint32_t s_misc[264];
+    __shared__ uint32_t s_misc[24];
     const SegRef r = locate_chunk(a);
-    for (int i = threadIdx.x; i < kBins; i += kHistThreads) s_hist[i] = 0;
-    uint32_t prefix = 0, need = r.k;
-    if (LEVEL > 0) thresholds(a, r, LEVEL, s_misc, prefix, need);
-    __syncthreads();
-    constexpr int U = kChunk / kHistThreads;       // 16 scores per thread, loaded up front
+    const int tid = threadIdx.x;
+#ifdef IA_SEL_PROFILE
+    const bool prof = (int)blockIdx.x == a.plan.chunk_off[r.l];
+#define FPROF(i) do { if (prof) SEL_PROF(0, r.l, i); } while (0)
+#else
+#define FPROF(i) do { } while (0)
+#endif
+    FPROF(0);
+    // this chunk's scores: requested first, their latency hides behind the threshold search
+    constexpr int U = kSelChunk / kFilterThreads;       // 16 scores per thread
     uint32_t key[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const uint32_t j = (uint32_t)u * kHistThreads + threadIdx.x;
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
         key[u] = (j < r.cnt) ? ordered_key(r.src[r.beg + j]) : 0u;
     }
+    // ---- v: a lower bound of the segment's k-th largest key from (a sample of) its group maxima
+    const int g = a.plan.grp[r.l];
+    int64_t first, count;
+    segment_groups(a.t, r.l, r.b, g, first, count);
+    const int64_t stride = (count + kMaxGroups - 1) / kMaxGroups;
+    const uint32_t used = count > 0 ? (uint32_t)((count + stride - 1) / stride) : 0u;
+    for (int i = tid; i < kBins; i += kFilterThreads) s_hist[i] = 0;
+    if (tid == 0) s_misc[16] = 0;                        // candidates of this chunk
+    uint32_t v = 0;
+    if (used >= r.k) {                                   // uniform
+        const float *gm = a.groupmax + a.plan.goff[r.l] + first;
+        uint32_t gk[kGroupsPerThread];
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int u = 0; u < kGroupsPerThread; ++u) {
+            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+            gk[u] = (j < used) ? ordered_key(gm[(int64_t)j * stride]) : 0u;
+        }
+        FPROF(1);
+#pragma unroll
+        for (int u = 0; u < kGroupsPerThread; ++u) {
+            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+            if (j < used) { lo = gk[u] < lo ? gk[u] : lo; hi = gk[u] > hi ? gk[u] : hi; }
+        }
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off), h2 = (uint32_t)__shfl_xor((int)hi, off);
+            lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+        }
+        if ((tid & 63) == 0) { s_misc[8 + (tid >> 6)] = lo; s_misc[12 + (tid >> 6)] = hi; }
+        __syncthreads();                                 // also: s_hist cleared
+#pragma unroll
+        for (int w = 0; w < kFilterThreads / kWave; ++w) {
+            lo = s_misc[8 + w] < lo ? s_misc[8 + w] : lo;
+            hi = s_misc[12 + w] > hi ? s_misc[12 + w] : hi;
+        }
+        const int shift = bin_shift(hi - lo);
+#pragma unroll
+        for (int u = 0; u < kGroupsPerThread; ++u) {
+            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+            if (j < used) atomicAdd(&s_hist[(gk[u] - lo) >> shift], 1u);
+        }
+        __syncthreads();
+        FPROF(2);
+        int d; uint32_t above, in_d;
+        find_bin_256(s_hist, r.k, s_misc, d, above, in_d);
+        v = lo + ((uint32_t)d << shift);                 // >= k group maxima are >= v
+        FPROF(3);
+    } else {
+        __syncthreads();
+    }
+    // ---- candidates of this chunk, into the chunk's own slice of the list
+    uint64_t *list = a.cand + (size_t)r.b * a.anchors_per_img + a.t.anchor_off[r.l] + r.beg;
+    uint32_t hits = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const uint32_t j = (uint32_t)u * kHistThreads + threadIdx.x;
-        bool act = j < r.cnt;
-        if (LEVEL == 1) act = act && (key[u] >> 21) == prefix;
-        if (LEVEL == 2) act = act && (key[u] >> 10) == prefix;
-        hist_add(s_hist, act, (uint32_t)digit_of(key[u], LEVEL));
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+        hits += ((j < r.cnt) && key[u] >= v) ? 1u : 0u;
+    }
+    uint32_t pos = hits ? atomicAdd(&s_misc[16], hits) : 0u;
+    FPROF(4);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+        if ((j < r.cnt) && key[u] >= v) {
+            const uint32_t i = r.beg + j;
+            // NCHW heads store the row maxima anchor-major (a, p); the reference's anchor index is
+            // p*A + a, which is the storage order itself for channels-last heads
+            const uint32_t an = i / r.HW, p = i - an * r.HW;
+            const uint32_t idx = r.natural ? i : (p * r.A + an);
+            list[pos++] = ((uint64_t)key[u] << 32) | (uint64_t)(0xffffffffu - idx);
+        }
     }
     __syncthreads();
-    uint32_t *g = a.hist + (((size_t)r.b * a.t.num_levels + r.l) * 3 + LEVEL) * kBins;
-    for (int i = threadIdx.x; i < kBins; i += kHistThreads)
-        if (s_hist[i]) atomicAdd(g + i, s_hist[i]);
+    if (tid == 0)
+        a.chunk_count[(size_t)r.b * a.total_chunks + a.plan.chunk_off[r.l] + r.chunk] = s_misc[16];
+    FPROF(5);
 }
 
-__global__ void __launch_bounds__(kHistThreads) k_sel_collect(SelArgs a)
-{
-    __shared__ uint32_t s_misc[264];
-    const SegRef r = locate_chunk(a);
-    uint32_t T, need;
-    thresholds(a, r, 3, s_misc, T, need);          // T: 32-bit key of the k-th largest score
-    uint64_t *sure = a.sure + (size_t)r.b * a.cands_per_img + a.t.cand_off[r.l];
-    uint32_t *ties = a.ties + (size_t)r.b * a.anchors_per_img + a.t.anchor_off[r.l];
-    uint32_t *cnt = a.counters + ((size_t)r.b * a.t.num_levels + r.l) * kCntStride;
-    constexpr int U = kChunk / kHistThreads;
-    uint32_t key[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t j = (uint32_t)u * kHistThreads + threadIdx.x;
-        key[u] = (j < r.cnt) ? ordered_key(r.src[r.beg + j]) : 0u;
-    }
-    // Slots: every wavefront round reserves its block in LDS counters (returning LDS atomics are
-    // cheap), ONE returning global atomic per workgroup and list reserves the workgroup's range.
-    // (One global atomic per wavefront round serialised on the few cache lines that hold the
-    // counters of all segments: 55 us for this kernel.)
-    uint32_t *s_cnt = s_misc + 8;                  // [0] above, [1] ties, [2],[3] global bases
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t off_up[U], off_eq[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t j = (uint32_t)u * kHistThreads + threadIdx.x;
-        const bool in = j < r.cnt;
-        const bool up = in && key[u] > T, eq = in && key[u] == T;
-        const uint64_t mu = __ballot(up), me = __ballot(eq);
-        off_up[u] = off_eq[u] = 0xffffffffu;
-        if (mu) {
-            uint32_t b0 = 0;
-            const int leader = __builtin_ctzll(mu);
-            if (lane_id() == leader) b0 = atomicAdd(&s_cnt[0], (uint32_t)__builtin_popcountll(mu));
-            b0 = (uint32_t)__shfl((int)b0, leader);
-            if (up) off_up[u] = b0 + lane_prefix_popc(mu);
-        }
-        if (me) {
-            uint32_t b0 = 0;
-            const int leader = __builtin_ctzll(me);
-            if (lane_id() == leader) b0 = atomicAdd(&s_cnt[1], (uint32_t)__builtin_popcountll(me));
-            b0 = (uint32_t)__shfl((int)b0, leader);
-            if (eq) off_eq[u] = b0 + lane_prefix_popc(me);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x])
-        s_cnt[2 + threadIdx.x] = atomicAdd(cnt + threadIdx.x, s_cnt[threadIdx.x]);
-    __syncthreads();
-    const uint32_t base_up = s_cnt[2], base_eq = s_cnt[3];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t j = (uint32_t)u * kHistThreads + threadIdx.x;
-        const uint32_t i = r.beg + j;
-        // NCHW heads store the row maxima anchor-major (a, p); the reference's anchor index is
-        // p*A + a, which is the storage order itself for channels-last heads
-        const uint32_t an = i / r.HW, p = i - an * r.HW;
-        const uint32_t idx = r.natural ? i : (p * r.A + an);
-        if (off_up[u] != 0xffffffffu)
-            sure[base_up + off_up[u]] = ((uint64_t)key[u] << 32) | (uint64_t)(0xffffffffu - idx);
-        if (off_eq[u] != 0xffffffffu) ties[base_eq + off_eq[u]] = idx;
-    }
-    if (blockIdx.x == (unsigned)a.chunk_off[r.l] && threadIdx.x == 0) {
-        // leave the threshold for the final kernel (one writer per segment)
-        a.hist[(((size_t)r.b * a.t.num_levels + r.l) * 3 + 2) * kBins + 1024] = T;
-        a.hist[(((size_t)r.b * a.t.num_levels + r.l) * 3 + 2) * kBins + 1025] = need;
-    }
-}
+extern __shared__ uint64_t s_dyn[];            // k_sel_final: sel / buckets | staged candidate keys
 
-__global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a)
+constexpr int kBucketCap = 128;            // keys per histogram bin the counting sort accepts
+
+__global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t p_max)
 {
-    __shared__ TopkScratch sc;
-    __shared__ uint64_t sel[IA_MAX_NMS_PRE];
+    __shared__ TopkScratch sc;                     // sc.hist: bin counts, then bucket fill counters
+    __shared__ uint32_t s_start[kBins + 1];        // keys in the bins above bin i
+    __shared__ uint32_t s_pre[kMaxSegChunks + 1];
+    __shared__ uint32_t s_red[40];
+    uint64_t *sel = s_dyn;                         // p_max + kBucketCap entries
+    uint64_t *stage = s_dyn + p_max + kBucketCap;
     const int l = blockIdx.x, b = blockIdx.y;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    SEL_PROF(1, l, 0);
     const uint32_t n = (uint32_t)(a.t.anchor_off[l + 1] - a.t.anchor_off[l]);
     const uint32_t k = (uint32_t)(a.t.cand_off[l + 1] - a.t.cand_off[l]);
     int32_t *out = a.cand_idx + (size_t)b * a.cands_per_img + a.t.cand_off[l];
     if (k == n) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = (int32_t)i;
+        for (uint32_t i = tid; i < n; i += nt) out[i] = (int32_t)i;
         return;
     }
-    const uint32_t *h2 = a.hist + (((size_t)b * a.t.num_levels + l) * 3 + 2) * kBins;
-    const uint32_t T = h2[1024], need = h2[1025];       // need = ties to take, 1 <= need <= n_tie
-    const uint32_t *cnt = a.counters + ((size_t)b * a.t.num_levels + l) * kCntStride;
-    const uint32_t n_sure = cnt[0], n_tie = cnt[1];     // n_sure + need == k
-    const uint64_t *sure = a.sure + (size_t)b * a.cands_per_img + a.t.cand_off[l];
-    const uint32_t *ties = a.ties + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
-    const uint32_t P = next_pow2(k);
-    // the ties that are taken: the `need` lowest anchor indices among the scores equal to T
-    // (usually need == n_tie == 1).  sel doubles as the selection's output buffer; the chosen
-    // keys wait in registers while sel is refilled with the keys above the threshold.
-    uint64_t mine[IA_MAX_NMS_PRE / kFinalThreads];
-    if (n_tie != need) {
-        block_topk_desc([ties, T](uint32_t i) -> uint64_t {
-                            return ((uint64_t)T << 32) | (uint64_t)(0xffffffffu - ties[i]); },
-                        n_tie, need, sc, sel);
-    }
-#pragma unroll
-    for (int u = 0; u < IA_MAX_NMS_PRE / kFinalThreads; ++u) {
-        const uint32_t i = (uint32_t)u * kFinalThreads + threadIdx.x;
-        mine[u] = 0ull;
-        if (i < need)
-            mine[u] = (n_tie != need) ? sel[i]
-                                      : (((uint64_t)T << 32) | (uint64_t)(0xffffffffu - ties[i]));
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) sel[i] = (i < n_sure) ? sure[i] : 0ull;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < IA_MAX_NMS_PRE / kFinalThreads; ++u) {
-        const uint32_t i = (uint32_t)u * kFinalThreads + threadIdx.x;
-        if (i < need) sel[n_sure + i] = mine[u];
-    }
-    __syncthreads();
-    bitonic_sort_desc(sel, P);
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x)
-        out[i] = (int32_t)(0xffffffffu - (uint32_t)sel[i]);
-}
-
-static void plan(const LevelTable &t, SelArgs &a)
-{
-    a.chunk_off[0] = 0;
-    for (int l = 0; l < IA_MAX_LEVELS; ++l) {
-        int chunks = 0;
-        if (l < t.num_levels) {
-            const int n = t.anchor_off[l + 1] - t.anchor_off[l];
-            const int k = t.cand_off[l + 1] - t.cand_off[l];
-            if (k < n) chunks = (n + kChunk - 1) / kChunk;
+    const bool filtered = a.plan.grp[l] != 0;
+    const float *src = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
+    const uint64_t *list = a.cand + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
+    const bool natural = a.t.layout == IA_LAYOUT_NHWC;
+    const uint32_t HW = (uint32_t)(a.t.H[l] * a.t.W[l]), A = (uint32_t)a.t.A;
+    // candidates: the filter's per-chunk slices, or the whole (small) level
+    uint32_t m = n;
+    uint32_t nchunks = 0;
+    if (filtered) {
+        nchunks = (uint32_t)(a.plan.chunk_off[l + 1] - a.plan.chunk_off[l]);
+        const uint32_t *cc = a.chunk_count + (size_t)b * a.total_chunks + a.plan.chunk_off[l];
+        if (tid < (uint32_t)kWave) {               // exclusive prefix of the chunk counts, wave 0
+            uint32_t carry = 0;
+            for (uint32_t c0 = 0; c0 < nchunks; c0 += kWave) {
+                const uint32_t c = c0 + tid;
+                const uint32_t v = c < nchunks ? cc[c] : 0u;
+                uint32_t incl = v;
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+                    if ((int)tid >= off) incl += u;
+                }
+                if (c < nchunks) s_pre[c] = carry + incl - v;
+                carry += (uint32_t)__shfl((int)incl, kWave - 1);
+            }
+            if (tid == 0) s_pre[nchunks] = carry;
         }
-        a.chunk_off[l + 1] = a.chunk_off[l] + chunks;
+        __syncthreads();
+        m = s_pre[nchunks];
     }
+    const uint32_t *pre = s_pre;
+    auto cand_key = [=](uint32_t i) -> uint64_t {
+        uint32_t lo = 0, hi = nchunks;                     // pre[lo] <= i < pre[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= i) lo = mid; else hi = mid;
+        }
+        return list[(size_t)lo * kSelChunk + (i - pre[lo])];
+    };
+    auto dense_key = [=](uint32_t i) -> uint64_t {
+        const uint32_t an = i / HW, p = i - an * HW;
+        const uint32_t idx = natural ? i : (p * A + an);
+        return ((uint64_t)ordered_key(src[i]) << 32) | (uint64_t)(0xffffffffu - idx);
+    };
+    bool general = m > (uint32_t)a.lds_cap;
+    if (!general) {
+        // ---- stage + minimum / maximum of the score words
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        if (filtered) {                            // a wavefront per chunk slice
+            for (uint32_t c = tid >> 6; c < nchunks; c += nt >> 6) {
+                const uint32_t base = pre[c], cnt = pre[c + 1] - base;
+                for (uint32_t j = tid & 63u; j < cnt; j += kWave) {
+                    const uint64_t x = list[(size_t)c * kSelChunk + j];
+                    stage[base + j] = x;
+                    const uint32_t w = (uint32_t)(x >> 32);
+                    lo = w < lo ? w : lo; hi = w > hi ? w : hi;
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < m; i += nt) {
+                const uint64_t x = dense_key(i);
+                stage[i] = x;
+                const uint32_t w = (uint32_t)(x >> 32);
+                lo = w < lo ? w : lo; hi = w > hi ? w : hi;
+            }
+        }
+        for (uint32_t i = tid; i < kBins; i += nt) sc.hist[i] = 0;
+        if (tid < 8) sc.misc[tid] = 0;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off), h2 = (uint32_t)__shfl_xor((int)hi, off);
+            lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+        }
+        if ((tid & 63) == 0) { s_red[tid >> 6] = lo; s_red[16 + (tid >> 6)] = hi; }
+        __syncthreads();
+        SEL_PROF(1, l, 1);
+        for (uint32_t w = 0; w < nt / kWave; ++w) {
+            lo = s_red[w] < lo ? s_red[w] : lo;
+            hi = s_red[16 + w] > hi ? s_red[16 + w] : hi;
+        }
+        // ---- histogram over linear bins between them
+        const int shift = bin_shift(hi - lo);
+        for (uint32_t i = tid; i < m; i += nt)
+            atomicAdd(&sc.hist[((uint32_t)(stage[i] >> 32) - lo) >> shift], 1u);
+        __syncthreads();
+        SEL_PROF(1, l, 2);
+        // ---- s_start[bin] = keys in the bins above it (two bins per thread, top bins first);
+        // the largest bucket among the bins that reach into the top k
+        {
+            const uint32_t top = kBins - 1 - 2 * tid;      // this thread: bins top, top - 1
+            const uint32_t c0 = sc.hist[top], c1 = sc.hist[top - 1];
+            const uint32_t s2 = c0 + c1;
+            uint32_t incl = s2;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+                if ((int)(tid & 63u) >= off) incl += u;
+            }
+            if ((tid & 63u) == 63u) s_red[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_red[w];
+            const uint32_t st0 = base + incl - s2, st1 = st0 + c0;
+            s_start[top] = st0; s_start[top - 1] = st1;
+            sc.hist[top] = 0; sc.hist[top - 1] = 0;        // now the buckets' fill counters
+            uint32_t big = (st0 < k ? c0 : 0u);
+            big = (st1 < k && c1 > big) ? c1 : big;
+            if (big > (uint32_t)kBucketCap) sc.misc[5] = 1;
+            if (st0 < k && st0 + c0 >= k) sc.misc[6] = st0 + c0;       // slots in use
+            if (st1 < k && st1 + c1 >= k) sc.misc[6] = st1 + c1;
+        }
+        __syncthreads();
+        SEL_PROF(1, l, 3);
+        if (sc.misc[5]) {
+            general = true;                                 // heavy ties: exact radix select below
+        } else {
+            // ---- counting sort of the keys of those bins: scatter into the bins' buckets ...
+            for (uint32_t i = tid; i < m; i += nt) {
+                const uint64_t x = stage[i];
+                const uint32_t bin = ((uint32_t)(x >> 32) - lo) >> shift;
+                const uint32_t st = s_start[bin];
+                if (st < k) sel[st + atomicAdd(&sc.hist[bin], 1u)] = x;
+            }
+            __syncthreads();
+            // ... then every key finds its place among the (few) keys of its bucket
+            const uint32_t slots = sc.misc[6];
+            for (uint32_t s0 = tid; s0 < slots; s0 += nt) {
+                const uint64_t x = sel[s0];
+                const uint32_t bin = ((uint32_t)(x >> 32) - lo) >> shift;
+                const uint32_t st = s_start[bin], en = bin ? s_start[bin - 1] : m;
+                uint32_t rank = 0;
+                for (uint32_t q = st; q < en; ++q) rank += (sel[q] > x) ? 1u : 0u;
+                if (st + rank < k) out[st + rank] = (int32_t)(0xffffffffu - (uint32_t)x);
+            }
+            SEL_PROF(1, l, 4);
+            return;
+        }
+    }
+    // ---- general path: exact MSB-first radix select + sort (ia_block.hpp)
+    __syncthreads();
+    if (m <= (uint32_t)a.lds_cap)                           // staged above
+        block_topk_desc([stage](uint32_t i) -> uint64_t { return stage[i]; }, m, k, sc, sel);
+    else if (filtered)
+        block_topk_desc(cand_key, m, k, sc, sel);
+    else
+        block_topk_desc(dense_key, m, k, sc, sel);
+    for (uint32_t i = tid; i < k; i += nt)
+        out[i] = (int32_t)(0xffffffffu - (uint32_t)sel[i]);
+    SEL_PROF(1, l, 15);
 }
 
-struct SelLayout { size_t hist, counters, sure, ties, total; };
+struct SelLayout { size_t chunk_count, groupmax, cand, total; };
 
-static SelLayout layout(const LevelTable &t, int batch)
+static SelLayout layout(const LevelTable &t, const SelPlan &p, int batch)
 {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     SelLayout w;
-    const size_t L = (size_t)t.num_levels, B = (size_t)batch;
+    const size_t B = (size_t)batch;
     size_t o = 0;
-    w.hist = o; o = up(o + B * L * 3 * kBins * sizeof(uint32_t));
-    w.counters = o; o = up(o + B * L * kCntStride * sizeof(uint32_t));
-    const size_t zeroed = o;                       // hist + counters are cleared per call
-    w.sure = o; o = up(o + B * (size_t)t.cand_off[t.num_levels] * sizeof(uint64_t));
-    w.ties = o; o = up(o + B * (size_t)t.anchor_off[t.num_levels] * sizeof(uint32_t));
-    w.total = o;
-    (void)zeroed;
+    w.chunk_count = o; o = up(o + B * (size_t)p.chunk_off[IA_MAX_LEVELS] * sizeof(uint32_t));
+    w.groupmax = o; o = up(o + (size_t)p.goff[IA_MAX_LEVELS] * sizeof(float));
+    w.cand = o;
+    if (p.chunk_off[IA_MAX_LEVELS] > 0)
+        o = up(o + B * (size_t)t.anchor_off[t.num_levels] * sizeof(uint64_t));
+    w.total = o > 0 ? o : 256;
     return w;
 }
 
 size_t select_workspace_bytes(const LevelTable &t, int batch)
 {
-    return layout(t, batch).total;
+    SelPlan p;
+    if (make_sel_plan(t, batch, p)) return 0;
+    return layout(t, p, batch).total;
+}
+
+float *select_workspace_groupmax(const LevelTable &t, int batch, void *workspace)
+{
+    SelPlan p;
+    if (make_sel_plan(t, batch, p)) return nullptr;
+    return reinterpret_cast<float *>(static_cast<char *>(workspace) + layout(t, p, batch).groupmax);
 }
 
 int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
-                  void *workspace, hipStream_t s)
+                  void *workspace, hipStream_t s, bool have_groups)
 {
     if (batch < 1 || !rowmax || !cand_idx || !workspace) return IA_E_ARG;
     SelArgs a;
-    a.t = t; a.rowmax = rowmax; a.cand_idx = cand_idx;
-    const SelLayout w = layout(t, batch);
+    a.t = t; a.rowmax = rowmax; a.cand_idx = cand_idx; a.batch = batch;
+    int rc = make_sel_plan(t, batch, a.plan);
+    if (rc) return rc;
+    const SelLayout w = layout(t, a.plan, batch);
     char *ws = static_cast<char *>(workspace);
-    a.hist = reinterpret_cast<uint32_t *>(ws + w.hist);
-    a.counters = reinterpret_cast<uint32_t *>(ws + w.counters);
-    a.sure = reinterpret_cast<uint64_t *>(ws + w.sure);
-    a.ties = reinterpret_cast<uint32_t *>(ws + w.ties);
+    float *groupmax = reinterpret_cast<float *>(ws + w.groupmax);
+    a.groupmax = groupmax;
+    a.chunk_count = reinterpret_cast<uint32_t *>(ws + w.chunk_count);
+    a.cand = reinterpret_cast<uint64_t *>(ws + w.cand);
     a.anchors_per_img = t.anchor_off[t.num_levels];
     a.cands_per_img = t.cand_off[t.num_levels];
-    plan(t, a);
-    const int chunks = a.chunk_off[t.num_levels];
-    if (chunks > 0) {
-        hipError_t e = hipMemsetAsync(ws + w.hist, 0, w.sure - w.hist, s);
+    a.total_chunks = a.plan.chunk_off[IA_MAX_LEVELS];
+    // LDS of the final kernel: sel (next_pow2 of the largest k) + staged candidates
+    uint32_t kmax = 1;
+    for (int l = 0; l < t.num_levels; ++l) {
+        const uint32_t n = (uint32_t)(t.anchor_off[l + 1] - t.anchor_off[l]);
+        const uint32_t k = (uint32_t)(t.cand_off[l + 1] - t.cand_off[l]);
+        if (k < n && k > kmax) kmax = k;
+        if (a.plan.chunk_off[l + 1] - a.plan.chunk_off[l] > kMaxSegChunks) return IA_E_ARG;
+    }
+    uint32_t p_max = 1;
+    while (p_max < kmax) p_max <<= 1;
+    a.lds_cap = kSelDenseMax;
+    const size_t dyn = ((size_t)p_max + kBucketCap + (size_t)a.lds_cap) * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        // up to 32 KiB (sel, k <= 4096) + 96 KiB (stage) + the static scratch: above the 64 KiB a
+        // kernel gets without asking
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sel_final),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((IA_MAX_NMS_PRE + kBucketCap + kSelDenseMax) * sizeof(uint64_t)));
         if (e != hipSuccess) return (int)e;
-        const dim3 grid((unsigned)chunks, (unsigned)batch), block(kHistThreads);
-        hipLaunchKernelGGL(k_sel_hist<0>, grid, block, 0, s, a);
-        hipLaunchKernelGGL(k_sel_hist<1>, grid, block, 0, s, a);
-        hipLaunchKernelGGL(k_sel_hist<2>, grid, block, 0, s, a);
-        hipLaunchKernelGGL(k_sel_collect, grid, block, 0, s, a);
-        int rc = hip_status(hipGetLastError());
+        attr_set = true;
+    }
+    const int chunks = a.total_chunks;
+    if (chunks > 0) {
+        if (!have_groups)
+            hipLaunchKernelGGL(k_sel_groupmax, dim3((unsigned)((a.plan.goff[IA_MAX_LEVELS] + 255) / 256)),
+                               dim3(256), 0, s, a, groupmax);
+        hipLaunchKernelGGL(k_sel_filter, dim3((unsigned)chunks, (unsigned)batch),
+                           dim3(kFilterThreads), 0, s, a);
+        rc = hip_status(hipGetLastError());
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
-                       dim3(kFinalThreads), 0, s, a);
+                       dim3(kFinalThreads), dyn, s, a, p_max);
     return hip_status(hipGetLastError());
 }
 

@@ -252,24 +252,41 @@ def geometry_for(geom, cls, reg, iou):
     return level_ptrs(geom, list(cls), list(reg), list(iou))[3]
 
 
-def decode_fuse_rowmax(geom, cls, reg, iou):
+def decode_fuse_rowmax(geom, cls, reg, iou, select_ws=None):
+    """select_ws: a top-k workspace (select_workspace): the kernel then also leaves the group
+    maxima / cleared counters select_topk(..., select_ws) starts from (ia_get_bboxes' chaining)"""
     cls, reg, iou = list(cls), list(reg), list(iou)
     p, B, dt, geom = level_ptrs(geom, cls, reg, iou)
     out = torch.empty((B, geom.N), dtype=torch.float32, device=cls[0].device)
-    _lib.check(_lib.lib().ia_decode_fuse_rowmax(geom.ref(), C.byref(p), B, dt, _ptr(out),
-                                                _stream()), 'ia_decode_fuse_rowmax')
+    if select_ws is None:
+        _lib.check(_lib.lib().ia_decode_fuse_rowmax(geom.ref(), C.byref(p), B, dt, _ptr(out),
+                                                    _stream()), 'ia_decode_fuse_rowmax')
+    else:
+        _lib.check(_lib.lib().ia_decode_fuse_rowmax_grouped(
+            geom.ref(), C.byref(p), B, dt, _ptr(out), _ptr(select_ws), select_ws.numel(),
+            _stream()), 'ia_decode_fuse_rowmax_grouped')
     return out
 
 
-def select_topk(geom, rowmax):
+def select_workspace(geom, batch, device):
+    nbytes = _lib.lib().ia_select_topk_workspace_bytes(geom.ref(), int(batch))
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+def select_topk(geom, rowmax, select_ws=None):
+    """select_ws: the workspace decode_fuse_rowmax(..., select_ws) has just filled"""
     _require_gpu(rowmax, 'rowmax')
     rowmax = rowmax.contiguous()
     B = rowmax.shape[0]
     out = torch.empty((B, geom.R), dtype=torch.int32, device=rowmax.device)
-    nbytes = _lib.lib().ia_select_topk_workspace_bytes(geom.ref(), B)
-    ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=rowmax.device)
-    _lib.check(_lib.lib().ia_select_topk(geom.ref(), _ptr(rowmax), B, _ptr(out), _ptr(ws), nbytes,
-                                         _stream()), 'ia_select_topk')
+    if select_ws is None:
+        ws = select_workspace(geom, B, rowmax.device)
+        _lib.check(_lib.lib().ia_select_topk(geom.ref(), _ptr(rowmax), B, _ptr(out), _ptr(ws),
+                                             ws.numel(), _stream()), 'ia_select_topk')
+    else:
+        _lib.check(_lib.lib().ia_select_topk_grouped(geom.ref(), _ptr(rowmax), B, _ptr(out),
+                                                     _ptr(select_ws), select_ws.numel(),
+                                                     _stream()), 'ia_select_topk_grouped')
     return out
 
 

@@ -234,6 +234,89 @@ def _stage_chain(ops, geom, dc, dr, di, shapes, sfs):
         assert torch.equal(a, b)
 
 
+def _numpy_topk(rowmax_ref_order, k):
+    """canonical order of the reference's topk (:536-544): score descending, anchor index
+    ascending among equal scores -- a stable argsort of the negated scores"""
+    return np.argsort(-rowmax_ref_order.astype(np.float64), kind='stable')[:k].astype(np.int32)
+
+
+SELECT_CASES = [
+    # pad_h, pad_w, batch, nms_pre, kind -- which top-k path the large levels take
+    (800, 1344, 2, 1000, 'A'),       # P3: groups of 64 (N % 64 = 32: groups straddle images), P4: of 16
+    (800, 1344, 2, 1000, 'D'),       # random-init-like near-ties: a handful of equal scores on every cut
+    (384, 480, 3, 1000, 'A'),        # P3 = 25 920 anchors: groups of 4, 6 480 of them -> sampled
+    (384, 480, 3, 1000, 'T'),        # few distinct values: thousands of ties on the cut
+    (384, 480, 2, 1000, 'E'),        # all scores equal: every anchor is a candidate (global path)
+    (384, 480, 2, 4096, 'A'),        # the largest nms_pre
+    (416, 472, 2, 300, 'A'),         # H*W of P3 = 52 * 59 (odd): the scalar-load branch of k_rowmax
+    (384, 480, 2, 1000, 'C'),        # clustered high scores: far more than k candidates per group
+]
+
+
+@pytest.mark.parametrize('ph,pw,B,nms_pre,kind', SELECT_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_select_topk_filtered_paths(ops, ph, pw, B, nms_pre, kind, dtype):
+    """the top-k behind the row-max kernel (group maxima -> filter -> exact select) on levels
+    large enough to be filtered, both memory orders, against a stable sort of the very row-max
+    array the device produced; the chained form (group maxima from the row-max kernel) and the
+    stage form (derived from the array by an extra pass) must agree"""
+    rs = np.random.RandomState(hash((ph, pw, kind)) % (2 ** 31))
+    sizes = synth.level_shapes(ph, pw)
+    cls, reg, iou = [], [], []
+    for (h, w) in sizes:
+        if kind in ('A', 'C'):
+            mu, sd, isd, _ = synth.SETS[kind]
+            c = rs.standard_normal((B, 720, h, w)) * sd + mu
+            i = rs.standard_normal((B, 9, h, w)) * isd
+            if kind == 'C':                  # blobs of high scores, 12 x 12 positions each
+                for b in range(B):
+                    for _ in range(6):
+                        y, x = rs.randint(0, max(h - 12, 1)), rs.randint(0, max(w - 12, 1))
+                        c[b, :, y:y + 12, x:x + 12] += 9.0
+        elif kind == 'D':
+            c = -4.595 + rs.standard_normal((B, 720, h, w)) * 0.0016
+            i = rs.standard_normal((B, 9, h, w)) * 0.0019
+        elif kind == 'T':
+            c = -4.595 + rs.randint(-3, 4, (B, 720, h, w)) * 0.0016
+            i = rs.randint(-2, 3, (B, 9, h, w)) * 0.0019
+        else:
+            c = np.full((B, 720, h, w), -4.595)
+            i = np.zeros((B, 9, h, w))
+        cls.append(c.astype(np.float32))
+        iou.append(i.astype(np.float32))
+        reg.append(np.zeros((B, 36, h, w), np.float32))
+    geom0, _ = G.geometry(ph, pw, nms_pre)
+    for channels_last in (True, False):
+        dc, dr, di = G.to_dev(cls, dtype), G.to_dev(reg, dtype), G.to_dev(iou, dtype)
+        if channels_last:
+            dc, dr, di = [[t.contiguous(memory_format=torch.channels_last) for t in x]
+                          for x in (dc, dr, di)]
+        geom = ops.geometry_for(geom0, dc, dr, di)
+        assert geom.layout == int(channels_last)
+        ws = ops.select_workspace(geom, B, dc[0].device)
+        rm = ops.decode_fuse_rowmax(geom, dc, dr, di, ws)
+        idx = ops.select_topk(geom, rm, ws).cpu().numpy()
+        rm2 = ops.decode_fuse_rowmax(geom, dc, dr, di)
+        idx2 = ops.select_topk(geom, rm2).cpu().numpy()
+        assert torch.equal(rm, rm2)
+        assert np.array_equal(idx, idx2), 'chained and stage forms differ'
+        rm = rm.cpu().numpy()
+        off = coff = 0
+        for (h, w) in sizes:
+            n_l = h * w * geom.A
+            k = min(n_l, nms_pre)
+            for b in range(B):
+                sc = rm[b, off:off + n_l]
+                if not channels_last:            # stored anchor-major -> reference order p*A + a
+                    sc = sc.reshape(geom.A, h * w).T.reshape(-1)
+                want = _numpy_topk(sc, k) if k < n_l else np.arange(n_l, dtype=np.int32)
+                got = idx[b, coff:coff + k]
+                assert np.array_equal(got, want), (channels_last, (h, w), b,
+                                                   int((got != want).sum()))
+            off += n_l
+            coff += k
+
+
 # ------------------------------------------------------------------ nms op
 def test_nms_op_golden_cases(ops, golden_dir):
     n = np.load(os.path.join(golden_dir, 'nms.npz'))

@@ -31,10 +31,11 @@ if os.environ.get('CL', '1') != '0':      # channels-last head outputs (what ben
 geom = ops.geometry_for(geom, cls, reg, iou)
 print('layout', 'NHWC' if geom.layout else 'NCHW')
 shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
+SEL_WS = ops.select_workspace(geom, B, cls[0].device)     # the chained form ia_get_bboxes uses
 def stage_times():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    ev[0].record(); rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)
-    ev[1].record(); idx = ops.select_topk(geom, rm)
+    ev[0].record(); rm = ops.decode_fuse_rowmax(geom, cls, reg, iou, SEL_WS)
+    ev[1].record(); idx = ops.select_topk(geom, rm, SEL_WS)
     ev[2].record(); boxes, st, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, sfs, True)
     ev[3].record(); out = ops.multiclass_nms(boxes, st, geom.R, 0.05, 0.5, 100, best_score=best)
     ev[4].record(); torch.cuda.synchronize()
