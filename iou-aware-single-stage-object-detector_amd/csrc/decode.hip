@@ -22,6 +22,7 @@
 // fp32 (exhaustively checked by tests/test_oracle_math.py), so the max over
 // classes is taken on the raw logits and the transcendental part runs once
 // per anchor instead of once per class.
+#include <type_traits>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 
@@ -63,12 +64,25 @@ template <> struct Lane<float> {
         f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     }
+    static __device__ __forceinline__ void load_cached(const float *p, float (&v)[4])
+    {
+        f32x4 q = *reinterpret_cast<const f32x4 *>(p);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
 };
 template <> struct Lane<uint16_t> {
     static constexpr int PPL = 8;
     static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[8])
     {
         u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        v[0] = from_bits(q.x << 16); v[1] = from_bits(q.x & 0xffff0000u);
+        v[2] = from_bits(q.y << 16); v[3] = from_bits(q.y & 0xffff0000u);
+        v[4] = from_bits(q.z << 16); v[5] = from_bits(q.z & 0xffff0000u);
+        v[6] = from_bits(q.w << 16); v[7] = from_bits(q.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void load_cached(const uint16_t *p, float (&v)[8])
+    {
+        u32x4 q = *reinterpret_cast<const u32x4 *>(p);
         v[0] = from_bits(q.x << 16); v[1] = from_bits(q.x & 0xffff0000u);
         v[2] = from_bits(q.y << 16); v[3] = from_bits(q.y & 0xffff0000u);
         v[4] = from_bits(q.z << 16); v[5] = from_bits(q.z & 0xffff0000u);
@@ -203,6 +217,10 @@ struct RowmaxNhwcArgs {
 };
 
 constexpr int kMaxVpr = 32;              // 16-byte vectors per row: C * sizeof(T) <= 512 bytes
+#ifndef IA_ROWMAX_BATCH
+#define IA_ROWMAX_BATCH 20
+#endif
+constexpr int kRowmaxBatch = IA_ROWMAX_BATCH;   // vector loads in flight per lane (tools/ubench/rowmax_bench.hip)
 
 template <typename T, int VPR_T>         // VPR_T = 0: run-time vectors per row
 __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
@@ -226,23 +244,37 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
     // class loads instead of following the barrier
     const int64_t g = r0 + ((lane < nrow) ? lane : (nrow - 1));
     const float il = load_f32<T>(static_cast<const T *>(a.p.iou[l]) + g);
-    auto body = [&](int k) {
-        const int f = k * 64 + lane;
-        const int fc = (f < nvec) ? f : (nvec - 1);             // loads are never predicated
-        float v[PPL];
-        Lane<T>::load(src + (size_t)fc * PPL, v);
-        float m = v[0];
+    // All loads of a batch are issued before the first one is consumed: written as one loop
+    // (load, reduce, LDS store per vector) the compiler waits for each load before issuing the
+    // next -- ONE kilobyte in flight per wavefront, a latency-bound kernel that only its 29
+    // wavefronts per CU kept near 6 TB/s.
+    auto batch = [&](int k0, auto nb_tag) {
+        constexpr int NB = decltype(nb_tag)::value;
+        float v[NB][PPL];
 #pragma unroll
-        for (int j = 1; j < PPL; ++j) m = (m < v[j]) ? v[j] : m;
-        const int row = f / vpr, c4 = f - row * vpr;
-        if (f < nvec) s_m[row * (vpr + 1) + c4] = m;
+        for (int u = 0; u < NB; ++u) {
+            const int f = (k0 + u) * 64 + lane;
+            const int fc = (f < nvec) ? f : (nvec - 1);         // loads are never predicated
+            Lane<T>::load(src + (size_t)fc * PPL, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int f = (k0 + u) * 64 + lane;
+            float m = v[u][0];
+#pragma unroll
+            for (int j = 1; j < PPL; ++j) m = (m < v[u][j]) ? v[u][j] : m;
+            const int row = f / vpr, c4 = f - row * vpr;
+            if (f < nvec) s_m[row * (vpr + 1) + c4] = m;
+        }
     };
     if (VPR_T) {
+        constexpr int NB = (VPR_T % kRowmaxBatch == 0) ? kRowmaxBatch : (VPR_T ? VPR_T : 1);
 #pragma unroll
-        for (int k = 0; k < VPR_T; ++k) body(k);
+        for (int k = 0; k < VPR_T; k += NB) batch(k, std::integral_constant<int, NB>());
     } else {
-#pragma unroll 4
-        for (int k = 0; k < vpr; ++k) body(k);
+        int k = 0;
+        for (; k + 4 <= vpr; k += 4) batch(k, std::integral_constant<int, 4>());
+        for (; k < vpr; ++k) batch(k, std::integral_constant<int, 1>());
     }
     __syncthreads();
     float score = 0.0f;                                     // scores are >= 0
@@ -252,7 +284,11 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
         for (int c4 = 1; c4 < vpr; ++c4) m = (m < sr[c4]) ? sr[c4] : m;
         const int b = (int)(g / n_l);
         const int i = (int)(g - (int64_t)b * n_l);
+#ifdef IA_ROWMAX_NOMATH                                      /* tools/ubench/rowmax_bench.hip only */
+        score = m * il;
+#else
         score = sqrt_sigmoidf_(m) * sqrt_sigmoidf_(il);
+#endif
         a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] = score;
     }
     if (a.groupmax) {
@@ -267,6 +303,10 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
         }
     }
 }
+
+// unused dynamic LDS per workgroup = an occupancy cap for the streaming kernel (tools/ubench/
+// rowmax_bench.hip sweeps it)
+int rowmax_nhwc_lds_pad = 0;
 
 static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
                               float *rowmax, hipStream_t s, float *groupmax)
@@ -292,12 +332,13 @@ static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int b
     }
     dim3 grid((unsigned)a.blk_off[t.num_levels]);
     const int vpr = t.C / ppl;
+    const size_t pad = (size_t)rowmax_nhwc_lds_pad;
     if (dtype == IA_F32) {
-        if (vpr == 20) hipLaunchKernelGGL((k_rowmax_nhwc<float, 20>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((k_rowmax_nhwc<float, 0>), grid, dim3(64), 0, s, a);
+        if (vpr == 20) hipLaunchKernelGGL((k_rowmax_nhwc<float, 20>), grid, dim3(64), pad, s, a);
+        else hipLaunchKernelGGL((k_rowmax_nhwc<float, 0>), grid, dim3(64), pad, s, a);
     } else {
-        if (vpr == 10) hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 10>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 0>), grid, dim3(64), 0, s, a);
+        if (vpr == 10) hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 10>), grid, dim3(64), pad, s, a);
+        else hipLaunchKernelGGL((k_rowmax_nhwc<uint16_t, 0>), grid, dim3(64), pad, s, a);
     }
     return hip_status(hipGetLastError());
 }
@@ -345,6 +386,75 @@ struct GatherArgs {
     int32_t R, Rs, rescale;
 };
 
+// delta2bbox of one candidate (reference mmdet/core/bbox/transforms.py:50-76) on the anchor
+// regenerated from (level, position, anchor), clamp to img_shape, true division by scale_factor
+__device__ __forceinline__ float4 decode_box(const GatherArgs &a, int b, float ba0, float ba1,
+                                             float ba2, float ba3, int W, int stride, int pos,
+                                             float r0, float r1, float r2, float r3)
+{
+    const int y = pos / W, x = pos - y * W;
+    const float sx = (float)(x * stride), sy = (float)(y * stride);
+    const float ax1 = ba0 + sx, ay1 = ba1 + sy, ax2 = ba2 + sx, ay2 = ba3 + sy;
+    const float max_ratio = 4.135166556742356f;
+    float dx = r0 * a.stds[0] + a.means[0];
+    float dy = r1 * a.stds[1] + a.means[1];
+    float dw = r2 * a.stds[2] + a.means[2];
+    float dh = r3 * a.stds[3] + a.means[3];
+    dw = (dw < -max_ratio) ? -max_ratio : dw;  dw = (dw > max_ratio) ? max_ratio : dw;
+    dh = (dh < -max_ratio) ? -max_ratio : dh;  dh = (dh > max_ratio) ? max_ratio : dh;
+    float px = (ax1 + ax2) * 0.5f;
+    float py = (ay1 + ay2) * 0.5f;
+    float pw = (ax2 - ax1) + 1.0f;
+    float ph = (ay2 - ay1) + 1.0f;
+    float gw = pw * expf_(dw);
+    float gh = ph * expf_(dh);
+    float gx = px + pw * dx;
+    float gy = py + ph * dy;
+    float x1 = (gx - gw * 0.5f) + 0.5f;
+    float y1 = (gy - gh * 0.5f) + 0.5f;
+    float x2 = (gx + gw * 0.5f) - 0.5f;
+    float y2 = (gy + gh * 0.5f) - 0.5f;
+    const float mx = a.img_hw[2 * b + 1] - 1.0f, my = a.img_hw[2 * b] - 1.0f;
+    x1 = (x1 < 0.0f) ? 0.0f : x1;  x1 = (x1 > mx) ? mx : x1;
+    y1 = (y1 < 0.0f) ? 0.0f : y1;  y1 = (y1 > my) ? my : y1;
+    x2 = (x2 < 0.0f) ? 0.0f : x2;  x2 = (x2 > mx) ? mx : x2;
+    y2 = (y2 < 0.0f) ? 0.0f : y2;  y2 = (y2 > my) ? my : y2;
+    if (a.rescale) {
+        const float *sf = a.scale_factor + 4 * b;
+        x1 = x1 / sf[0]; y1 = y1 / sf[1]; x2 = x2 / sf[2]; y2 = y2 / sf[3];
+    }
+    return make_float4(x1, y1, x2, y2);
+}
+
+// Per-lane level lookup without per-lane memory traffic.  Indexing the kernel-argument tables
+// with a per-lane level (`a.t.cand_off[l]`, `a.p.cls[l]`, ...) compiles to VECTOR loads from the
+// kernarg segment: the old `while (r >= cand_off[l + 1]) ++l` was a chain of up to L dependent
+// memory round trips, followed by more for H, W and the three pointers (most of the gather
+// kernels' 17-20 us).  With constant indices the tables are scalar loads and the per-lane part is
+// compares and selects.
+struct LevelSel { int l, H, W, stride; const void *cls, *reg, *iou; };
+
+// MAXL: levels the caller guarantees at most (the per-level scalars of all MAXL levels stay live
+// in SGPRs: 8 levels cost 90 SGPRs, which caps the residency at 7 wavefronts per SIMD)
+template <int MAXL = IA_MAX_LEVELS>
+__device__ __forceinline__ LevelSel level_of_candidate(const GatherArgs &a, int r)
+{
+    LevelSel s;
+    s.l = 0;
+#pragma unroll
+    for (int i = 1; i < MAXL; ++i)
+        s.l += (i < a.t.num_levels && r >= a.t.cand_off[i]) ? 1 : 0;
+    s.H = a.t.H[0]; s.W = a.t.W[0]; s.stride = a.t.stride[0];
+    s.cls = a.p.cls[0]; s.reg = a.p.reg[0]; s.iou = a.p.iou[0];
+#pragma unroll
+    for (int i = 1; i < MAXL; ++i) {
+        const bool m = s.l == i;
+        s.H = m ? a.t.H[i] : s.H; s.W = m ? a.t.W[i] : s.W; s.stride = m ? a.t.stride[i] : s.stride;
+        s.cls = m ? a.p.cls[i] : s.cls; s.reg = m ? a.p.reg[i] : s.reg; s.iou = m ? a.p.iou[i] : s.iou;
+    }
+    return s;
+}
+
 constexpr int kGroups = 4;   // class groups per candidate (threadIdx.y)
 
 template <typename T>
@@ -357,18 +467,18 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
     const bool live = r_raw < a.R;
     const int r = live ? r_raw : a.R - 1;        // clamp: every thread reaches the barrier
     const int A = a.t.A, C = a.t.C;
-    int l = 0;
-    while (r >= a.t.cand_off[l + 1]) ++l;
-    const int W = a.t.W[l], HW = a.t.H[l] * W;
+    const LevelSel lv = level_of_candidate(a, r);
+    const int l = lv.l;
+    const int W = lv.W, HW = lv.H * W;
     const int idx = a.cand_idx[(size_t)b * a.R + r];
     const int pos = idx / A, an = idx - pos * A;
     // channel stride / element offsets of candidate (pos, an) in either memory order
     const bool nhwc = a.t.layout == IA_LAYOUT_NHWC;
     const size_t cs = nhwc ? (size_t)1 : (size_t)HW;
     const size_t row = ((size_t)b * HW + pos) * A + an;                  // (B, HW, A) row id
-    const T *cls = static_cast<const T *>(a.p.cls[l]) +
+    const T *cls = static_cast<const T *>(lv.cls) +
                    (nhwc ? row * C : ((size_t)b * A + an) * C * HW + pos);
-    const T *iou = static_cast<const T *>(a.p.iou[l]) +
+    const T *iou = static_cast<const T *>(lv.iou) +
                    (nhwc ? row : ((size_t)b * A + an) * HW + pos);
     const float sq_iou = sqrt_sigmoidf_(load_f32<T>(iou));
     const int cpg = (C + kGroups - 1) / kGroups;
@@ -391,43 +501,104 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
             for (int g2 = 1; g2 < kGroups; ++g2) best = (best < gmax[g2][lane]) ? gmax[g2][lane] : best;
             a.best_score[(size_t)b * a.R + r] = best;
         }
-        const T *reg = static_cast<const T *>(a.p.reg[l]) +
+        const T *reg = static_cast<const T *>(lv.reg) +
                        (nhwc ? row * 4 : ((size_t)b * A + an) * 4 * HW + pos);
-        const int y = pos / W, x = pos - y * W;
-        const float sx = (float)(x * a.t.stride[l]), sy = (float)(y * a.t.stride[l]);
         const float *ba = a.ba.v[l][an];
-        const float ax1 = ba[0] + sx, ay1 = ba[1] + sy, ax2 = ba[2] + sx, ay2 = ba[3] + sy;
-        // delta2bbox, reference mmdet/core/bbox/transforms.py:50-76
-        const float max_ratio = 4.135166556742356f;
-        float dx = load_f32<T>(reg) * a.stds[0] + a.means[0];
-        float dy = load_f32<T>(reg + cs) * a.stds[1] + a.means[1];
-        float dw = load_f32<T>(reg + 2 * cs) * a.stds[2] + a.means[2];
-        float dh = load_f32<T>(reg + 3 * cs) * a.stds[3] + a.means[3];
-        dw = (dw < -max_ratio) ? -max_ratio : dw;  dw = (dw > max_ratio) ? max_ratio : dw;
-        dh = (dh < -max_ratio) ? -max_ratio : dh;  dh = (dh > max_ratio) ? max_ratio : dh;
-        float px = (ax1 + ax2) * 0.5f;
-        float py = (ay1 + ay2) * 0.5f;
-        float pw = (ax2 - ax1) + 1.0f;
-        float ph = (ay2 - ay1) + 1.0f;
-        float gw = pw * expf_(dw);
-        float gh = ph * expf_(dh);
-        float gx = px + pw * dx;
-        float gy = py + ph * dy;
-        float x1 = (gx - gw * 0.5f) + 0.5f;
-        float y1 = (gy - gh * 0.5f) + 0.5f;
-        float x2 = (gx + gw * 0.5f) - 0.5f;
-        float y2 = (gy + gh * 0.5f) - 0.5f;
-        const float mx = a.img_hw[2 * b + 1] - 1.0f, my = a.img_hw[2 * b] - 1.0f;
-        x1 = (x1 < 0.0f) ? 0.0f : x1;  x1 = (x1 > mx) ? mx : x1;
-        y1 = (y1 < 0.0f) ? 0.0f : y1;  y1 = (y1 > my) ? my : y1;
-        x2 = (x2 < 0.0f) ? 0.0f : x2;  x2 = (x2 > mx) ? mx : x2;
-        y2 = (y2 < 0.0f) ? 0.0f : y2;  y2 = (y2 > my) ? my : y2;
-        if (a.rescale) {
-            const float *sf = a.scale_factor + 4 * b;
-            x1 = x1 / sf[0]; y1 = y1 / sf[1]; x2 = x2 / sf[2]; y2 = y2 / sf[3];
-        }
-        reinterpret_cast<float4 *>(a.boxes)[(size_t)b * a.R + r] = make_float4(x1, y1, x2, y2);
+        reinterpret_cast<float4 *>(a.boxes)[(size_t)b * a.R + r] =
+            decode_box(a, b, ba[0], ba[1], ba[2], ba[3], W, lv.stride, pos, load_f32<T>(reg), load_f32<T>(reg + cs),
+                       load_f32<T>(reg + 2 * cs), load_f32<T>(reg + 3 * cs));
     }
+}
+
+// ---------------------------------------------------------------------------
+// Channels-last head outputs: a candidate's C logits are one contiguous run (320 B for C = 80
+// fp32).  A workgroup takes kGTile = 32 candidates with vpr / VT threads per candidate (vpr = C *
+// sizeof(T) / 16 vectors per row, VT = 2 of them per thread when vpr is even): every thread loads
+// its 16-byte vectors (a wavefront instruction reads whole rows), turns the logits into fused
+// scores, and the scores go through an LDS tile so that the class-major score rows are written as
+// contiguous 128-byte runs; the first thread of a candidate also decodes its box.  At batch 8:
+// 1 176 workgroups of 5 wavefronts, all resident at once (64 SGPRs: the per-level scalars of 5
+// levels; with 8 levels' worth, 90 SGPRs, only 4 workgroups fit a CU and the tail ran as a second
+// round).  The thread-per-20-classes kernel before it: 19 us.
+constexpr int kGTile = 32;
+
+#ifdef IA_GATHER_PROFILE
+__device__ unsigned long long g_gather_prof[4][16];
+__device__ unsigned long long g_gather_blk[8][160][4];      // per block: start, end of wave 0, end of last wave, XCC id
+#define GPROF(i) do { if (threadIdx.x == 0 && blockIdx.x % 49 == 0 && blockIdx.y == 3) g_gather_prof[blockIdx.x / 49][i] = wall_clock64(); \
+    if (threadIdx.x == 0 && (i) == 0) g_gather_blk[blockIdx.y][blockIdx.x][0] = wall_clock64(); \
+    if (threadIdx.x == 0 && (i) == 5) g_gather_blk[blockIdx.y][blockIdx.x][1] = wall_clock64(); \
+    if (threadIdx.x == blockDim.x - 1 && (i) == 5) g_gather_blk[blockIdx.y][blockIdx.x][2] = wall_clock64(); } while (0)
+#else
+#define GPROF(i) do { } while (0)
+#endif
+
+template <typename T, int VT, int MAXL>
+__global__ void __launch_bounds__(1024) k_gather_nhwc(GatherArgs a, int tpc)
+{
+    constexpr int PPL = Lane<T>::PPL;
+    extern __shared__ float s_tile[];            // [C][kGTile + 1] fused scores
+    __shared__ uint32_t s_best[kGTile];          // max over classes (bits of a float >= 0)
+    const int tid = threadIdx.x, b = blockIdx.y;
+    GPROF(0);
+    const int A = a.t.A, C = a.t.C;
+    const int r0 = blockIdx.x * kGTile;
+    const int cand = tid / tpc, w = tid - cand * tpc;          // blockDim.x == kGTile * tpc
+    if (tid < kGTile) s_best[tid] = 0u;
+    // every thread resolves its candidate itself (the threads of a candidate read the same words:
+    // one broadcast request): the only dependent memory round trips of the kernel are
+    // candidate index -> {class vectors, IoU logit, box deltas}
+    const int r_raw = r0 + cand;
+    const int r = r_raw < a.R ? r_raw : a.R - 1;
+    const LevelSel lv = level_of_candidate<MAXL>(a, r);
+    const int idx = a.cand_idx[(size_t)b * a.R + r];
+    GPROF(1);
+    const int pos = idx / A, an = idx - pos * A;
+    const size_t row = ((size_t)b * lv.H * lv.W + pos) * A + an;       // (B, HW, A) row id
+    float x[VT][PPL];
+#pragma unroll
+    for (int u = 0; u < VT; ++u)
+        Lane<T>::load_cached(static_cast<const T *>(lv.cls) + row * C + (w + u * tpc) * PPL, x[u]);
+    const float iou = load_f32<T>(static_cast<const T *>(lv.iou) + row);
+    // the first thread of a candidate also decodes its box (a few lanes of every wavefront,
+    // ahead of the barrier, rather than one wavefront's worth behind it)
+    const bool boxer = w == 0 && r_raw < a.R;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, ba0 = 0.0f, ba1 = 0.0f, ba2 = 0.0f, ba3 = 0.0f;
+    if (boxer) {
+        const T *reg = static_cast<const T *>(lv.reg) + row * 4;
+        d0 = load_f32<T>(reg); d1 = load_f32<T>(reg + 1); d2 = load_f32<T>(reg + 2); d3 = load_f32<T>(reg + 3);
+        const float *ba = a.ba.v[lv.l][an];
+        ba0 = ba[0]; ba1 = ba[1]; ba2 = ba[2]; ba3 = ba[3];
+    }
+    GPROF(2);
+    const float sq = sqrt_sigmoidf_(iou);
+    float best = 0.0f;                                          // scores are >= 0
+#pragma unroll
+    for (int u = 0; u < VT; ++u)
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const float sc = sqrt_sigmoidf_(x[u][j]) * sq;
+            s_tile[((w + u * tpc) * PPL + j) * (kGTile + 1) + cand] = sc;
+            best = (best < sc) ? sc : best;
+        }
+    if (boxer)
+        reinterpret_cast<float4 *>(a.boxes)[(size_t)b * a.R + r] =
+            decode_box(a, b, ba0, ba1, ba2, ba3, lv.W, lv.stride, pos, d0, d1, d2, d3);
+    GPROF(3);
+    __syncthreads();                                            // s_best cleared, tile written
+    atomicMax(&s_best[cand], to_bits(best));
+    __syncthreads();
+    GPROF(4);
+    const int nlive = (a.R - r0 < kGTile) ? (a.R - r0) : kGTile;
+    // class-major rows, kGTile contiguous floats each
+    float *so = a.scores_t + (size_t)b * C * a.Rs + r0;
+    for (int q = tid; q < C * kGTile; q += blockDim.x) {
+        const int c = q / kGTile, j = q - c * kGTile;
+        if (j < nlive) so[(size_t)c * a.Rs + j] = s_tile[c * (kGTile + 1) + j];
+    }
+    if (tid < nlive && a.best_score)
+        a.best_score[(size_t)b * a.R + r0 + tid] = from_bits(s_best[tid]);
+    GPROF(5);
 }
 
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
@@ -443,6 +614,33 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
     a.cand_idx = cand_idx; a.img_hw = img_hw; a.scale_factor = scale_factor;
     a.boxes = boxes; a.scores_t = scores_t; a.best_score = best_score;
     a.R = t.cand_off[t.num_levels]; a.Rs = Rs; a.rescale = rescale;
+    if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    const int esz = dtype == IA_F32 ? 4 : 2;
+    if (t.layout == IA_LAYOUT_NHWC && (t.C * esz) % 16 == 0 && t.C * esz / 16 <= kMaxVpr) {
+        bool aligned = true;
+        for (int l = 0; l < t.num_levels; ++l) aligned = aligned && (((uintptr_t)p.cls[l] & 15u) == 0);
+        if (aligned) {
+            const int vpr = t.C * esz / 16;
+            const dim3 grid((unsigned)((a.R + kGTile - 1) / kGTile), (unsigned)batch);
+            const size_t lds = (size_t)t.C * (kGTile + 1) * sizeof(float);
+            const bool two = vpr % 2 == 0;
+            const int tpc = two ? vpr / 2 : vpr;               // threads per candidate
+            const dim3 block((unsigned)(kGTile * tpc));
+            const bool few = t.num_levels <= 5;                 // the usual P3..P7 pyramid
+#define IA_GATHER_LAUNCH(TT, VT)                                                                  \
+    do {                                                                                          \
+        if (few) hipLaunchKernelGGL((k_gather_nhwc<TT, VT, 5>), grid, block, lds, s, a, tpc);      \
+        else hipLaunchKernelGGL((k_gather_nhwc<TT, VT, IA_MAX_LEVELS>), grid, block, lds, s, a, tpc); \
+    } while (0)
+            if (dtype == IA_F32) {
+                if (two) IA_GATHER_LAUNCH(float, 2); else IA_GATHER_LAUNCH(float, 1);
+            } else {
+                if (two) IA_GATHER_LAUNCH(uint16_t, 2); else IA_GATHER_LAUNCH(uint16_t, 1);
+            }
+#undef IA_GATHER_LAUNCH
+            return hip_status(hipGetLastError());
+        }
+    }
     dim3 block(64, kGroups);
     dim3 grid((unsigned)((a.R + 63) / 64), (unsigned)batch);
     if (dtype == IA_F32) hipLaunchKernelGGL(k_gather<float>, grid, block, 0, s, a);

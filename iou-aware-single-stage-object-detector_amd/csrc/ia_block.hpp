@@ -113,7 +113,7 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = base + u * nt + tid;
-                xs[u] = (i < n) ? key(i) : 0;
+                xs[u] = key(i < n ? i : n - 1);     // never predicated: see select.hip
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -170,7 +170,7 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t i = base + u * nt + tid;
-                    xs[u] = (i < n) ? key(i) : 0;
+                    xs[u] = key(i < n ? i : n - 1);     // never predicated: see select.hip
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -215,7 +215,7 @@ __device__ void block_topk_desc(KeyFn key, uint32_t n, uint32_t k, TopkScratch &
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             const uint32_t i = base + u * nt + tid;
-            xs[u] = (i < n) ? key(i) : 0;
+            xs[u] = key(i < n ? i : n - 1);     // never predicated: see select.hip
         }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {

@@ -35,7 +35,8 @@
 
 // phase timestamps for tools/ubench/select_bench.hip (compiled out of the library)
 #ifdef IA_SEL_PROFILE
-namespace ia { __device__ unsigned long long g_sel_prof[2][IA_MAX_LEVELS][24]; }
+namespace ia { __device__ unsigned long long g_sel_prof[2][IA_MAX_LEVELS][24];
+               __device__ unsigned long long g_sel_blk[2][16][64][2]; }   // per-block start / end
 #define SEL_PROF(kern, lvl, i)                                                        \
     do { if (blockIdx.y == 0 && threadIdx.x == 0) ia::g_sel_prof[kern][lvl][i] = wall_clock64(); } while (0)
 #define IA_BLOCK_PROF(i) SEL_PROF(1, blockIdx.x, i)
@@ -49,7 +50,7 @@ namespace ia {
 constexpr int kFilterThreads = 256;
 constexpr int kBins = 2048;
 constexpr int kFinalThreads = 1024;
-constexpr int kMaxGroups = 4096;           // group maxima a filter workgroup looks at
+constexpr int kMaxGroups = 4096;           // group maxima a filter workgroup looks at (2^12)
 constexpr int kGroupsPerThread = kMaxGroups / kFilterThreads;
 constexpr int kMaxSegChunks = 1024;        // filter chunks per segment (N_l <= 4 M anchors)
 
@@ -133,16 +134,18 @@ __device__ __forceinline__ SegRef locate_chunk(const SelArgs &a)
 }
 
 // the groups that lie completely inside segment (b, l): [first, first + count) of the level's array
+// (g is 4, 16 or 64: shifts, no 64-bit divisions)
 __device__ __forceinline__ void segment_groups(const LevelTable &t, int l, int b, int g,
                                                int64_t &first, int64_t &count)
 {
+    const int lg = 31 - __builtin_clz((unsigned)g);
     const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
     if (t.layout == IA_LAYOUT_NHWC) {
-        first = ((int64_t)b * n + g - 1) / g;
-        const int64_t end = ((int64_t)(b + 1) * n) / g;
+        first = ((int64_t)b * n + g - 1) >> lg;
+        const int64_t end = ((int64_t)(b + 1) * n) >> lg;
         count = end > first ? end - first : 0;
     } else {
-        const int64_t gpp = ((int64_t)t.H[l] * t.W[l] + g - 1) / g;
+        const int64_t gpp = ((int64_t)t.H[l] * t.W[l] + g - 1) >> lg;
         first = (int64_t)b * t.A * gpp;
         count = (int64_t)t.A * gpp;
     }
@@ -196,32 +199,40 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
 #define FPROF(i) do { } while (0)
 #endif
     FPROF(0);
+#ifdef IA_SEL_PROFILE
+    if (tid == 0 && blockIdx.y < 16 && blockIdx.x < 64) g_sel_blk[0][blockIdx.y][blockIdx.x][0] = wall_clock64();
+#endif
     // this chunk's scores: requested first, their latency hides behind the threshold search
     constexpr int U = kSelChunk / kFilterThreads;       // 16 scores per thread
-    uint32_t key[U];
+    // (loads are never predicated -- out-of-range lanes read a clamped address: a predicated load
+    // compiles to branch + load + s_waitcnt, i.e. 16 serialised round trips)
+    float kf[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const uint32_t j = (uint32_t)u * kFilterThreads + tid;
-        key[u] = (j < r.cnt) ? ordered_key(r.src[r.beg + j]) : 0u;
+        kf[u] = r.src[r.beg + (j < r.cnt ? j : r.cnt - 1)];
     }
     // ---- v: a lower bound of the segment's k-th largest key from (a sample of) its group maxima
     const int g = a.plan.grp[r.l];
     int64_t first, count;
     segment_groups(a.t, r.l, r.b, g, first, count);
-    const int64_t stride = (count + kMaxGroups - 1) / kMaxGroups;
-    const uint32_t used = count > 0 ? (uint32_t)((count + stride - 1) / stride) : 0u;
+    const uint32_t stride = (uint32_t)((count + kMaxGroups - 1) >> 12);        // kMaxGroups = 4096
+    const uint32_t used = count > 0 ? ((uint32_t)count + stride - 1) / stride : 0u;
     for (int i = tid; i < kBins; i += kFilterThreads) s_hist[i] = 0;
     if (tid == 0) s_misc[16] = 0;                        // candidates of this chunk
     uint32_t v = 0;
     if (used >= r.k) {                                   // uniform
         const float *gm = a.groupmax + a.plan.goff[r.l] + first;
+        float gf[kGroupsPerThread];
         uint32_t gk[kGroupsPerThread];
         uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
         for (int u = 0; u < kGroupsPerThread; ++u) {
             const uint32_t j = (uint32_t)u * kFilterThreads + tid;
-            gk[u] = (j < used) ? ordered_key(gm[(int64_t)j * stride]) : 0u;
+            gf[u] = gm[(size_t)(j < used ? j : used - 1) * stride];
         }
+#pragma unroll
+        for (int u = 0; u < kGroupsPerThread; ++u) gk[u] = ordered_key(gf[u]);
         FPROF(1);
 #pragma unroll
         for (int u = 0; u < kGroupsPerThread; ++u) {
@@ -255,6 +266,9 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
     } else {
         __syncthreads();
     }
+    uint32_t key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) key[u] = ordered_key(kf[u]);
     // ---- candidates of this chunk, into the chunk's own slice of the list
     uint64_t *list = a.cand + (size_t)r.b * a.anchors_per_img + a.t.anchor_off[r.l] + r.beg;
     uint32_t hits = 0;
@@ -281,6 +295,9 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
     if (tid == 0)
         a.chunk_count[(size_t)r.b * a.total_chunks + a.plan.chunk_off[r.l] + r.chunk] = s_misc[16];
     FPROF(5);
+#ifdef IA_SEL_PROFILE
+    if (tid == 0 && blockIdx.y < 16 && blockIdx.x < 64) g_sel_blk[0][blockIdx.y][blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 extern __shared__ uint64_t s_dyn[];            // k_sel_final: sel / buckets | staged candidate keys
@@ -363,11 +380,23 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
                 }
             }
         } else {
-            for (uint32_t i = tid; i < m; i += nt) {
-                const uint64_t x = dense_key(i);
-                stage[i] = x;
-                const uint32_t w = (uint32_t)(x >> 32);
-                lo = w < lo ? w : lo; hi = w > hi ? w : hi;
+            constexpr int DU = 4;                  // unpredicated loads, DU in flight per thread
+            for (uint32_t base = 0; base < m; base += nt * DU) {
+                uint64_t xs[DU];
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const uint32_t i = base + (uint32_t)u * nt + tid;
+                    xs[u] = dense_key(i < m ? i : m - 1);
+                }
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const uint32_t i = base + (uint32_t)u * nt + tid;
+                    if (i < m) {
+                        stage[i] = xs[u];
+                        const uint32_t w = (uint32_t)(xs[u] >> 32);
+                        lo = w < lo ? w : lo; hi = w > hi ? w : hi;
+                    }
+                }
             }
         }
         for (uint32_t i = tid; i < kBins; i += nt) sc.hist[i] = 0;

@@ -82,5 +82,21 @@ int main(int argc, char **argv)
             printf("   total %.2f\n", (double)(last - prof[kk][l][0]) * 0.01);
         }
     }
+    {
+        static unsigned long long blk[2][16][64][2];
+        CK(hipMemcpyFromSymbol(blk, HIP_SYMBOL(ia::g_sel_blk), sizeof(blk)));
+        unsigned long long t0 = ~0ull, t1 = 0; double sum = 0, mx = 0; int nb = 0;
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < 47; ++c) {
+                const unsigned long long s = blk[0][b][c][0], e = blk[0][b][c][1];
+                t0 = s < t0 ? s : t0; t1 = e > t1 ? e : t1;
+                sum += (e - s) * 0.01; mx = (e - s) * 0.01 > mx ? (e - s) * 0.01 : mx; ++nb;
+            }
+        printf("k_sel_filter blocks: first start -> last end %.2f us; block time avg %.2f max %.2f us; last start - first start %.2f us\n",
+               (t1 - t0) * 0.01, sum / nb, mx, 0.0);
+        unsigned long long smax = 0;
+        for (int b = 0; b < B; ++b) for (int c = 0; c < 47; ++c) smax = blk[0][b][c][0] > smax ? blk[0][b][c][0] : smax;
+        printf("  start skew (last start - first start) %.2f us\n", (smax - t0) * 0.01);
+    }
     return bad != 0;
 }
