@@ -113,17 +113,15 @@ def metas(batch):
 
 
 class Stepper(object):
-    """one benchmark step, with HIP events around the row-max kernel"""
+    """one benchmark step = the product path: network forward + ops.get_bboxes (one fused C-ABI
+    call for the whole post-conv path) (+ the all-gather when N > 1).  No events, no stage-wise
+    launches inside the timed region; the roofline figures come from decode_stage_roofline()."""
 
     def __init__(self, model, imgs, world):
         self.model, self.imgs, self.world = model, imgs, world
         self.metas = metas(imgs.shape[0])
         self.cfg = model.test_cfg
-        self.rowmax_ms, self.stage_ms = [], []
-        self.pending, self.count = [], 0
         self.last = None
-        self.nhwc = False
-        self.sel_ws = None
 
     @torch.no_grad()
     def step(self, timed=False):
@@ -137,49 +135,54 @@ class Stepper(object):
     def local_detections(self, timed=False):
         m = self.model
         cls, reg, iou = m.forward_head(self.imgs)
-        head = m.bbox_head
-        geom = head.geometry([tuple(c.shape[-2:]) for c in cls], self.cfg.get('nms_pre', -1))
+        geom = m.bbox_head.geometry([tuple(c.shape[-2:]) for c in cls], self.cfg.get('nms_pre', -1))
         shapes = [x['img_shape'] for x in self.metas]
         factors = [x['scale_factor'] for x in self.metas]
-        if timed:
-            # same kernels as ops.get_bboxes, launched stage by stage so that HIP events on the
-            # launch stream bracket the row-max kernel alone.  Channels-last head outputs are
-            # consumed in place (k_rowmax_nhwc); NCHW ones by k_rowmax.
-            geom = ops.geometry_for(geom, cls, reg, iou)
-            self.nhwc = bool(geom.layout)
-            # one pair of events per step (an event between two kernels costs the dependent
-            # launch ~10-30 us): even steps bracket the row-max kernel, odd steps the whole
-            # decode stage
-            self.count += 1
-            stage = self.count % 2 == 1
-            e0, e1 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            e0.record()
-            if self.sel_ws is None:
-                self.sel_ws = ops.select_workspace(geom, cls[0].shape[0], cls[0].device)
-            rm = ops.decode_fuse_rowmax(geom, cls, reg, iou, self.sel_ws)
-            if not stage:
-                e1.record()
-            idx = ops.select_topk(geom, rm, self.sel_ws)
-            boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors,
-                                                      True)
-            if stage:
-                e1.record()
-            self.pending.append((stage, e0, e1))
-            dets, labels, rows, num = ops.multiclass_nms_lazy(boxes, scores_t, geom.R,
-                                                              self.cfg.score_thr,
-                                                              self.cfg.nms.iou_thr,
-                                                              self.cfg.max_per_img, best_score=best)
-        else:
-            dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
-                                                     self.cfg.score_thr, self.cfg.nms.iou_thr,
-                                                     self.cfg.max_per_img)
+        dets, labels, rows, num = ops.get_bboxes(geom, cls, reg, iou, shapes, factors, True,
+                                                 self.cfg.score_thr, self.cfg.nms.iou_thr,
+                                                 self.cfg.max_per_img)
         return dets, labels, num, cls, reg, iou
 
-    def collect(self):
+
+@torch.no_grad()
+def decode_stage_roofline(stepper, reps=10, rounds=5):
+    """SURVEY 8(d)'s decode stage on the head outputs of the last step, after the timed region:
+    the same kernels ops.get_bboxes launches (row-max with group maxima -> top-k filter -> top-k
+    final -> gather / decode), `reps` passes back to back between ONE pair of HIP events on the
+    launch stream (an event pair costs 3-7 us, and an event between two kernels delays the
+    dependent launch), best of `rounds`; then the row-max kernel alone the same way.
+    -> (ms per stage pass, ms per row-max launch, channels-last?)"""
+    cls, reg, iou = stepper.last[3:6]
+    m = stepper.model
+    geom = m.bbox_head.geometry([tuple(c.shape[-2:]) for c in cls], stepper.cfg.get('nms_pre', -1))
+    geom = ops.geometry_for(geom, cls, reg, iou)
+    shapes = [x['img_shape'] for x in stepper.metas]
+    factors = [x['scale_factor'] for x in stepper.metas]
+    ws = ops.select_workspace(geom, cls[0].shape[0], cls[0].device)
+
+    def stage():
+        rm = ops.decode_fuse_rowmax(geom, cls, reg, iou, ws)
+        idx = ops.select_topk(geom, rm, ws)
+        return ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors, True)
+
+    def rowmax():
+        return ops.decode_fuse_rowmax(geom, cls, reg, iou, ws)
+
+    def best_of(fn):
+        fn()
         torch.cuda.synchronize()
-        for stage, e0, e1 in self.pending:
-            (self.stage_ms if stage else self.rowmax_ms).append(e0.elapsed_time(e1))
-        self.pending = []
+        best = None
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            best = t if best is None or t < best else best
+        return best
+    return best_of(stage), best_of(rowmax), bool(geom.layout)
 
 
 def cpu_model_name():
@@ -331,7 +334,10 @@ def wino_roofline(stepper, steps=2):
     winograd.TIMING = []
     try:
         for _ in range(steps):
-            stepper.step(timed=False)
+            # rank 0 alone runs these extra passes: no collective in here (stepper.step would
+            # all-gather and hang the other ranks)
+            with torch.no_grad():
+                stepper.local_detections()
         torch.cuda.synchronize()
         rec = [(k, e0.elapsed_time(e1), b) for k, e0, e1, b in winograd.TIMING]
     finally:
@@ -640,24 +646,15 @@ def main():
     def step():
         stepper.step(timed=True)
 
-    def warm():
-        # warm-up outside the timed region, and its event records dropped
-        for _ in range(args.warmup):
-            step()
-        stepper.collect()
-        stepper.rowmax_ms, stepper.stage_ms = [], []
-    warm()
-    elapsed = timed_region(step, args.steps, 0, world, sync, barrier, device)
-    stepper.collect()
+    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device)
 
     wino = wino_roofline(stepper) if rank == 0 and dtype == torch.float32 else None
     if rank == 0:
         esz = 4 if dtype == torch.float32 else 2
         n_img = batch * world * args.steps
-        ms_rowmax = float(np.mean(stepper.rowmax_ms))
-        ms_stage = float(np.mean(stepper.stage_ms))
+        ms_stage, ms_rowmax, nhwc = decode_stage_roofline(stepper)
         tname = 'float' if esz == 4 else 'unsigned short'
-        rm_kernel = ('ia::k_rowmax_nhwc<%s, %d>' % (tname, 80 * esz // 16) if stepper.nhwc
+        rm_kernel = ('ia::k_rowmax_nhwc<%s, %d>' % (tname, 80 * esz // 16) if nhwc
                      else 'ia::k_rowmax<%s>' % tname)
         rowmax_bytes = ((64512000 + 806400) * esz // 4 + 806400) * batch
         stage_bytes = HEAD_BYTES_PER_IMAGE * esz // 4 * batch
@@ -683,8 +680,11 @@ def main():
             # SURVEY 8(d)'s unit: the decode stage (row-max + top-k + gather), cls + reg + iou
             # logits read once = 68 544 000 B per fp32 image; the row-max kernel alone below it
             'roofline': {'bound': 'hbm',
-                         'kernel': 'decode stage: row-max + top-k select + gather/decode '
+                         'kernel': 'decode stage: k_rowmax + k_sel_filter + k_sel_final + k_gather '
                                    '(SURVEY 8d unit)',
+                         'timing': 'HIP events on the launch stream around 10 back-to-back passes '
+                                   'of the stage after the timed region, best of 5 (inter-kernel '
+                                   'gaps included; kernel-busy time: profiles/)',
                          'achieved': round(stage, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(stage / HBM_PEAK_GBS, 4),
                          'traffic': stage_traffic() if headline else None,

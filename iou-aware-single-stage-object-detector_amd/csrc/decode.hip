@@ -211,7 +211,7 @@ struct RowmaxNhwcArgs {
     ia_level_ptrs p;
     float *rowmax;
     int32_t blk_off[IA_MAX_LEVELS + 1];   // prefix of ceil(B * N_l / 64), levels in REVERSE order
-    int32_t batch, anchors_per_img;
+    int32_t batch, anchors_per_img, big_first;
     SelPlan plan;                         // see RowmaxArgs
     float *groupmax;
 };
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
     int rem = blockIdx.x, rl = 0;
     while (rem >= a.blk_off[rl + 1]) ++rl;
     rem -= a.blk_off[rl];
-    const int l = L - 1 - rl;
+    const int l = a.big_first ? rl : L - 1 - rl;
     const int vpr = VPR_T ? VPR_T : a.t.C / PPL;
     const int n_l = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
     const int64_t rows = (int64_t)a.batch * n_l;
@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
 // unused dynamic LDS per workgroup = an occupancy cap for the streaming kernel (tools/ubench/
 // rowmax_bench.hip sweeps it)
 int rowmax_nhwc_lds_pad = 0;
+int rowmax_nhwc_big_first = 1;           // block order: largest level first (-2 us: the latency-bound small levels fill the tail)
 
 static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
                               float *rowmax, hipStream_t s, float *groupmax)
@@ -320,8 +321,9 @@ static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int b
     int prc = make_sel_plan(t, batch, a.plan);
     if (prc) return prc;
     a.blk_off[0] = 0;
+    a.big_first = rowmax_nhwc_big_first;
     for (int rl = 0; rl < IA_MAX_LEVELS; ++rl) {
-        const int l = t.num_levels - 1 - rl;
+        const int l = a.big_first ? (rl < t.num_levels ? rl : -1) : t.num_levels - 1 - rl;
         int64_t n = 0;
         if (l >= 0) {
             if (((uintptr_t)p.cls[l] & 15u) != 0) return IA_E_ARG;      // 16-byte vector loads

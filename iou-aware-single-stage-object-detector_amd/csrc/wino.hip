@@ -63,21 +63,45 @@ __device__ __forceinline__ int xcd_tile(int bid, int T)
     return (bid & 7) * per + (bid >> 3);
 }
 
-__device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t)
+// The tables are read with constant indices (scalar loads) and the per-lane level is resolved
+// with compares and selects: a per-lane index into a kernel-argument array compiles to vector
+// loads from the kernarg segment, and `while (t >= tile_off[l + 1]) ++l` to a chain of them --
+// several dependent memory round trips in front of the first pixel load.
+__device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t, int *Hout = nullptr,
+                                               int *Wout = nullptr)
 {
     TileRef r;
     int l = 0;
-    while (t >= w.tile_off[l + 1]) ++l;
-    const int q = t - w.tile_off[l];
-    r.l = l; r.b = q / w.tpi[l];
-    const int i = q - r.b * w.tpi[l];
+#pragma unroll
+    for (int i = 1; i < IA_MAX_LEVELS; ++i) l += (i < w.L && t >= w.tile_off[i]) ? 1 : 0;
+    int off = w.tile_off[0], tpi = w.tpi[0], tx = w.tx[0], H = w.H[0], W = w.W[0];
+#pragma unroll
+    for (int i = 1; i < IA_MAX_LEVELS; ++i) {
+        const bool m = l == i;
+        off = m ? w.tile_off[i] : off; tpi = m ? w.tpi[i] : tpi; tx = m ? w.tx[i] : tx;
+        H = m ? w.H[i] : H; W = m ? w.W[i] : W;
+    }
+    if (Hout) *Hout = H;
+    if (Wout) *Wout = W;
+    const int q = t - off;
+    r.l = l; r.b = q / tpi;
+    const int i = q - r.b * tpi;
     // row-major tiles.  (Strips of 8 tile rows, column-major inside -- meant to shorten the L2
     // reuse distance of the overlapping 6x6 patches -- measured SLOWER: 260 vs 245 us for the
     // head's input transform, 222 vs 209 us for the output transform: neighbouring wavefronts
     // then touch DRAM pages a whole pixel row apart.)
-    const int ty = i / w.tx[l];
-    r.y0 = 4 * ty; r.x0 = 4 * (i - ty * w.tx[l]);
+    const int ty = i / tx;
+    r.y0 = 4 * ty; r.x0 = 4 * (i - ty * tx);
     return r;
+}
+
+template <typename P>
+__device__ __forceinline__ P level_ptr(P const (&tab)[IA_MAX_LEVELS], int l)
+{
+    P p = tab[0];
+#pragma unroll
+    for (int i = 1; i < IA_MAX_LEVELS; ++i) p = (l == i) ? tab[i] : p;
+    return p;
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -162,34 +186,53 @@ __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
     const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
-    const TileRef r = locate_tile(a.lv, t);
-    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
-    const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
+    int H, W;
+    const TileRef r = locate_tile(a.lv, t, &H, &W);
+    const float *x = level_ptr(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
     const bool pre = a.pre_shift != nullptr;
     float4 ps = f4(1.0f), pb = f4(0.0f);
     if (pre) {
         if (a.pre_scale) ps = *reinterpret_cast<const float4 *>(a.pre_scale + c);
         pb = *reinterpret_cast<const float4 *>(a.pre_shift + c);
     }
+    // All 36 loads are issued before anything consumes them.  (With the pre-activation's
+    // `if (pre)` inside the load loop the compiler emitted load, branch, s_waitcnt vmcnt(0) 36
+    // times over: ONE kilobyte in flight per wavefront at 3 wavefronts per SIMD.)
     float4 d[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int y = r.y0 - 1 + i;
+        const int yc = (y >= 0 && y < H) ? y : 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = r.x0 - 1 + j;
+            const int xc = (xx >= 0 && xx < W) ? xx : 0;
+            // unconditional (clamped address); padding is selected afterwards
+            d[i][j] = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
+        }
+    }
+    if (pre) {
+        const bool relu = a.pre_relu != 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float4 v = d[i][j];
+                v = make_float4(v.x * ps.x + pb.x, v.y * ps.y + pb.y, v.z * ps.z + pb.z, v.w * ps.w + pb.w);
+                const float4 z = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f,
+                                             v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+                d[i][j] = relu ? z : v;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int y = r.y0 - 1 + i;
         const bool yin = (y >= 0) && (y < H);
-        const int yc = yin ? y : 0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xx = r.x0 - 1 + j;
             const bool in = yin && (xx >= 0) && (xx < W);
-            const int xc = (xx >= 0 && xx < W) ? xx : 0;
-            // the load is unconditional (clamped address); padding is selected afterwards
-            float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)yc * W + xc) * a.Ctot);
-            if (pre) {
-                v = make_float4(v.x * ps.x + pb.x, v.y * ps.y + pb.y, v.z * ps.z + pb.z, v.w * ps.w + pb.w);
-                if (a.pre_relu) v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f,
-                                                v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
-            }
-            d[i][j] = in ? v : f4(0.0f);
+            d[i][j] = in ? d[i][j] : f4(0.0f);
         }
     }
     float4 tmp[6][6];
@@ -236,9 +279,9 @@ __global__ void __launch_bounds__(64) k_wino_dy(WinoInArgs a)
     const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
-    const TileRef r = locate_tile(a.lv, t);
-    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
-    const float *x = a.x[r.l] + (size_t)r.b * H * W * a.Ctot + c;
+    int H, W;
+    const TileRef r = locate_tile(a.lv, t, &H, &W);
+    const float *x = level_ptr(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
     float4 d[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -295,8 +338,8 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
     const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
-    const TileRef r = locate_tile(a.lv, t);
-    const int H = a.lv.H[r.l], W = a.lv.W[r.l];
+    int H, W;
+    const TileRef r = locate_tile(a.lv, t, &H, &W);
     const int g = c / a.Cg, cc = c - g * a.Cg;
     const float *m = a.M + ((size_t)g * 36 * a.T + t) * a.Cg + cc;
     const size_t kstride = (size_t)a.T * a.Cg;
