@@ -103,6 +103,43 @@ def _match_sets(want, got):
     return matched, total, worst_b, worst_s
 
 
+def _explain_unmatched(want, got, logit_err, gaps=None):
+    """Every reference detection without a counterpart within TOL must have a stated reason, or
+    the test fails (round 2 accepted `matched >= total - 2 / - 5` without looking at WHICH ones):
+      near-tol  a detection of the same class differs by at most 2 x TOL in one coordinate: the
+                accumulated fp32 convolution error of ~60-110 layers touches the tolerance;
+      near-cut  its score lies within 8 x the measured head-logit error (relative) of the
+                reference's 100th score: rank 100 / 101 may swap (`gaps`: the fixture's own
+                relative gaps between consecutive survivors, when it stores them).
+    -> (lines for the report, number unexplained)"""
+    scores = np.concatenate([w[:, 4] for w in want if len(w)]) if any(len(w) for w in want) else np.zeros(0)
+    cut = float(scores.min()) if scores.size else 0.0
+    margin = 8.0 * max(logit_err, 1e-7)
+    lines, bad = [], 0
+    for c, (w, g) in enumerate(zip(want, got)):
+        used = np.zeros(len(g), bool)
+        for d in w:
+            err = np.abs(g.astype(np.float64) - d.astype(np.float64)) / np.maximum(1.0, np.abs(d.astype(np.float64))) \
+                if len(g) else np.zeros((0, 5))
+            ok = (err <= TOL).all(1) & ~used if len(g) else np.zeros(0, bool)
+            if ok.any():
+                used[int(np.argmax(ok))] = True
+                continue
+            rel_to_cut = (float(d[4]) - cut) / max(float(d[4]), 1e-30)
+            near = (err.max(1).min() if len(g) else np.inf)
+            if near <= 2 * TOL:
+                lines.append('class %d score %.4f: nearest own detection off by %.2f x TOL (near-tol)'
+                             % (c, d[4], near / TOL))
+            elif rel_to_cut <= margin:
+                lines.append('class %d score %.6f: %.1e above the cut score, margin %.1e (near-cut)'
+                             % (c, d[4], rel_to_cut, margin))
+            else:
+                lines.append('class %d score %.4f box %s: UNEXPLAINED (nearest %.2e, %.1e above the cut)'
+                             % (c, d[4], d[:4].tolist(), near, rel_to_cut))
+                bad += 1
+    return lines, bad
+
+
 _REPORT = []
 
 
@@ -181,11 +218,15 @@ def test_image_to_detections_matches_reference(golden_dir, name, path):
                                            same_ids, len(theirs), topk_same,
                                            list(geom.level_cands)))
     assert n_got == n
-    # every reference detection whose rank is decided by a score gap larger than the measured
-    # head-output error must be present; the fixture's cut gap (100th vs 101st survivor) and NMS
-    # decisions near the IoU threshold are the only legitimate sources of a differing detection
-    assert matched >= total - 2, (matched, total)
-    assert same_ids >= len(theirs) - 2, (same_ids, len(theirs))
+    # every reference detection must be matched, or be explained (tolerance touched / rank 100
+    # vs 101 within the measured head-output error); kept anchor ids may differ only by as many
+    why, bad = _explain_unmatched(want, result, worst, f['det_score_gaps'])
+    for line in why:
+        _REPORT.append('      %s %s: %s' % (name, path, line))
+    assert bad == 0, why
+    assert matched + len(why) == total
+    near_cut = sum('near-cut' in w for w in why)
+    assert same_ids >= len(theirs) - near_cut, (same_ids, len(theirs), why)
 
 
 def test_reference_call_signature_variants(golden_dir):
@@ -216,7 +257,8 @@ def test_reference_call_signature_variants(golden_dir):
     # set-wise (two detections of a class with scores 1e-6 apart may swap between two forwards)
     scaled = [np.concatenate([a[:, :4] * sf, a[:, 4:]], 1) for a in r0]
     matched, total, _, _ = _match_sets(scaled, r2)
-    assert total == 100 and matched >= total - 1, (matched, total)
+    why, bad = _explain_unmatched(scaled, r2, 1e-6)
+    assert total == 100 and bad == 0 and matched + len(why) == total, (matched, total, why)
     # batch of two through the same entry point: a list of per-image results
     with torch.no_grad():
         two = m(return_loss=False, rescale=True, img=[torch.cat([x, x])], img_meta=[[meta, meta]])
@@ -290,7 +332,8 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
                 assert e <= TOL, (name, tag, e)
     for d, d0 in zip(wino_dets, ref_dets):
         matched, total, _, _ = _match_sets(d0, d)
-        assert total > 0 and matched >= total - 2, (name, matched, total)
+        why, bad = _explain_unmatched(d0, d, TOL)        # the paths agree within TOL (asserted above)
+        assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
 
 
 @pytest.mark.parametrize('path', ['module', 'winograd'])
@@ -334,8 +377,13 @@ def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
                    '(worst box %.2e, score %.2e)' % (name, path, worst, worst / TOL, matched, total,
                                                      wb, ws))
     assert worst <= TOL, (name, path, worst)
-    # ~110 layers: a few box coordinates come within 10 % of the tolerance (0.03 px at x = 300)
-    assert total == 100 and matched >= total - 5, (matched, total)
+    # ~110 layers: a few box coordinates come within 10 % of the tolerance (0.03 px at x = 300);
+    # a detection that is not matched within TOL must be explained (near-tol <= 2 x TOL, or rank
+    # 100 / 101 within the measured logit error) -- no count-based slack
+    why, bad = _explain_unmatched(want, result, worst)
+    for line in why:
+        _REPORT.append('      %s %s: %s' % (name, path, line))
+    assert total == 100 and bad == 0 and matched + len(why) == total, (matched, total, why)
 
 
 def test_config3_bf16_batch16_post_conv_path(oracle_lib):

@@ -318,18 +318,33 @@ def test_training_iteration_vs_the_reference(route, golden_dir):
     assert abs(float(total.detach().sum()) - float(f['total'])) <= 1e-4 * float(f['total'])
     grads = {k: p.grad for k, p in model.named_parameters()}
     assert sorted(k for k, p in model.named_parameters() if not p.requires_grad) == sorted(f['frozen'].tolist())
-    worst = 0.0
+    # Bounds = 4-5 x what MI355X measures (profiles/r03_train_parity_report.txt: norms 6.0e-5 /
+    # 6.7e-5, sampled entries 2.5e-4 / 8.1e-4 on the fused / module route): the gradients go
+    # through ~60 convolutions whose fp32 sums are reassociated (Winograd, split-K GEMMs); a
+    # flat 5e-3 / 1e-2 (round 2) would have hidden a 30-fold regression
+    NORM_TOL, SAMPLED_TOL = 3e-4, 3e-3
+    worst = worst_s = 0.0
+    worst_name = ''
     for name, want in zip(f['grad_names'].tolist(), f['grad_norms']):
         g = grads[name]
         assert g is not None, name
         got = float(g.double().norm())
         worst = max(worst, abs(got - want) / max(want, 1e-12))
-        assert abs(got - want) <= 5e-3 * max(want, 1e-12), (name, got, want)
+        assert abs(got - want) <= NORM_TOL * max(want, 1e-12), (name, got, want)
     for key in f.files:
         if key.startswith('gidx/'):
             name = key[5:]
             idx, want = f[key], f['gval/' + name].astype(np.float64)
             got = grads[name].detach().reshape(-1).cpu().numpy().astype(np.float64)[idx]
             err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
-            assert err <= 1e-2, (name, err)
-    print('worst gradient-norm deviation from the reference: %.2e (%s)' % (worst, route))
+            worst_s = max(worst_s, err)
+            worst_name = name if err == worst_s else worst_name
+            assert err <= SAMPLED_TOL, (name, err)
+    line = ('training iteration vs the reference (%s): worst gradient-norm deviation %.2e '
+            '(bound %.0e), worst sampled-entry deviation (norm-wise) %.2e at %s (bound %.0e)'
+            % (route, worst, NORM_TOL, worst_s, worst_name, SAMPLED_TOL))
+    print(line)
+    out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'train_parity_report_%s.txt' % route), 'w') as fh:
+            fh.write(line + '\n')

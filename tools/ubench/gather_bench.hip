@@ -10,6 +10,11 @@
 #include "../../iou-aware-single-stage-object-detector_amd/csrc/decode.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+__global__ void k_touch(int32_t *p, size_t n)       // rewrites the candidate list like the top-k kernel would
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] + 0;
+}
+
 __global__ void k_fill(float *p, size_t n, float mu, float sd)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -68,12 +73,16 @@ int main(int argc, char **argv)
     auto run = [&] { return ia::launch_gather(t, ba, g.means, g.stds, p, B, IA_F32, cand, hw, sf, 1, boxes, scores, best, Rs, 0); };
     for (int i = 0; i < 3; ++i) if (run()) { printf("launch failed\n"); return 1; }
     CK(hipDeviceSynchronize());
+    float *flush; const size_t fl = (size_t)1 << 28;      // 1 GiB: evicts L2 and the Infinity Cache
+    CK(hipMalloc(&flush, fl * 4));
+    const bool cold = argc > 2;
     float tot = 0;
     for (int i = 0; i < iters; ++i) {
+        if (cold) { k_fill<<<4096, 256>>>(flush, fl, 0.f, 1.f); k_touch<<<40, 1024>>>(cand, (size_t)B * R); }
         CK(hipEventRecord(e0)); run(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
     }
-    printf("launch_gather: %.1f us per call (events, one launch at a time)\n", tot / iters * 1e3);
+    printf("launch_gather (%s caches): %.1f us per call (events, one launch at a time)\n", cold ? "cold" : "warm", tot / iters * 1e3);
 #ifdef IA_GATHER_PROFILE
     unsigned long long prof[4][16];
     CK(hipMemcpyFromSymbol(prof, HIP_SYMBOL(ia::g_gather_prof), sizeof(prof)));
