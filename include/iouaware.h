@@ -47,6 +47,11 @@ extern "C" {
 
 #define IA_E_ARG (-1)        /* invalid argument / unsupported size */
 #define IA_E_WORKSPACE (-2)  /* workspace too small */
+/* a size above what the kernels are built for; the reference ops have no such limits
+ * (mmdet/ops/nms/src/nms_cpu.cpp:4-59 takes any n) -- the caller can tell them apart: */
+#define IA_E_LIMIT_BOXES (-3)    /* more than IA_MAX_CANDIDATES boxes / candidates in one call */
+#define IA_E_LIMIT_NMS_PRE (-4)  /* nms_pre above IA_MAX_NMS_PRE */
+#define IA_E_LIMIT_PER_IMG (-5)  /* max_per_img above IA_MAX_PER_IMG */
 
 /* Static geometry of one head for one padded input size. */
 typedef struct ia_head_geom {

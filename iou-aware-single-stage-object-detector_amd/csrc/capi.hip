@@ -24,7 +24,7 @@ static int ws_layout(const ia_head_geom *g, int batch, WsLayout &w)
     if (batch < 1) return IA_E_ARG;
     w.N = t.anchor_off[t.num_levels];
     w.R = t.cand_off[t.num_levels];
-    if (w.R > IA_MAX_CANDIDATES) return IA_E_ARG;
+    if (w.R > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
     w.Rs = (w.R + 63) / 64 * 64;
     size_t o = 0;
     const size_t B = (size_t)batch, C = (size_t)t.C;

@@ -23,7 +23,7 @@ inline int make_level_table(const ia_head_geom *g, LevelTable &t)
     if (g->num_levels < 1 || g->num_levels > IA_MAX_LEVELS) return IA_E_ARG;
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS) return IA_E_ARG;
     if (g->num_classes < 1 || g->num_classes > 4096) return IA_E_ARG;
-    if (g->nms_pre > IA_MAX_NMS_PRE) return IA_E_ARG;
+    if (g->nms_pre > IA_MAX_NMS_PRE) return IA_E_LIMIT_NMS_PRE;
     if (g->layout != IA_LAYOUT_NCHW && g->layout != IA_LAYOUT_NHWC) return IA_E_ARG;
     t.layout = g->layout;
     t.num_levels = g->num_levels; t.A = g->num_anchors; t.C = g->num_classes; t.nms_pre = g->nms_pre;

@@ -244,8 +244,9 @@ int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R,
                     void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
                     int32_t *need_full, hipStream_t s)
 {
-    if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || Rs < R || C < 1 || max_per_img < 1 ||
-        max_per_img > IA_MAX_PER_IMG)
+    if (R > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
+    if (max_per_img > IA_MAX_PER_IMG) return IA_E_LIMIT_PER_IMG;
+    if (batch < 1 || R < 1 || Rs < R || C < 1 || max_per_img < 1)
         return IA_E_ARG;
     if ((uint64_t)C * (uint64_t)Rs > 0x7fffffffull) return IA_E_ARG;
     if (!boxes || !scores_t || !workspace || !dets || !labels || !rows || !num || !need_full)

@@ -343,7 +343,8 @@ int launch_nms(const float *boxes, const float *scores_t, const float *best_scor
                int R, int Rs, int C, float score_thr, float iou_thr, void *workspace,
                int32_t *keep_count, int32_t *keep_rows, hipStream_t s, const int32_t *gate)
 {
-    if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || C < 1 || Rs < R) return IA_E_ARG;
+    if (R > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
+    if (batch < 1 || R < 1 || C < 1 || Rs < R) return IA_E_ARG;
     if (!boxes || !scores_t || !workspace || !keep_count || !keep_rows) return IA_E_ARG;
     size_t off[3];
     nms_workspace_bytes(batch, R, C, off);
@@ -401,7 +402,8 @@ size_t nms_single_workspace_bytes(int n)
 int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
                       void *workspace, size_t workspace_bytes, hipStream_t s)
 {
-    if (n < 0 || n > IA_MAX_CANDIDATES || !count) return IA_E_ARG;
+    if (n > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
+    if (n < 0 || !count) return IA_E_ARG;
     if (n == 0) return hip_status(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     if (!dets || !keep || !workspace) return IA_E_ARG;
     size_t off[3];
@@ -592,7 +594,8 @@ int launch_finalize(const float *boxes, const float *scores_t, const int32_t *ke
                     void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
                     hipStream_t s, const int32_t *gate)
 {
-    if (batch < 1 || C < 1 || C > kFinalMaxC || max_per_img < 1 || max_per_img > IA_MAX_PER_IMG)
+    if (max_per_img > IA_MAX_PER_IMG) return IA_E_LIMIT_PER_IMG;
+    if (batch < 1 || C < 1 || C > kFinalMaxC || max_per_img < 1)
         return IA_E_ARG;
     if (!dets || !labels || !rows || !num || !workspace) return IA_E_ARG;
     FinalKeyArgs k;

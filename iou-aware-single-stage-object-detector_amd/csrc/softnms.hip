@@ -272,7 +272,8 @@ int launch_soft_nms(const float *boxes, const float *scores_t, int batch, int R,
                     float score_thr, float iou_thr, int method, float sigma, float min_score,
                     int32_t *keep_count, int32_t *keep_rows, float *soft_scores, hipStream_t s)
 {
-    if (batch < 1 || R < 1 || R > IA_MAX_CANDIDATES || Rs < R || C < 1) return IA_E_ARG;
+    if (R > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
+    if (batch < 1 || R < 1 || Rs < R || C < 1) return IA_E_ARG;
     if (!boxes || !scores_t || !keep_count || !keep_rows || !soft_scores) return IA_E_ARG;
     if (!(sigma != 0.0f)) return IA_E_ARG;                  // ZeroDivisionError in the reference
     SoftArgs a;
@@ -332,7 +333,8 @@ int launch_soft_nms_single(const float *dets, int n, float iou_thr, int method, 
                            float min_score, float *out_dets, int32_t *out_inds, int32_t *count,
                            hipStream_t s)
 {
-    if (n < 0 || n > IA_MAX_CANDIDATES || !count) return IA_E_ARG;
+    if (n > IA_MAX_CANDIDATES) return IA_E_LIMIT_BOXES;
+    if (n < 0 || !count) return IA_E_ARG;
     if (!(sigma != 0.0f)) return IA_E_ARG;
     if (n == 0) {
         hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), s);

@@ -185,8 +185,12 @@ def lib():
     return _lib
 
 
+_ERRORS = {-1: 'argument error', -2: 'workspace too small',
+           -3: 'more than %d boxes / candidates in one call (IA_E_LIMIT_BOXES)' % 8192,
+           -4: 'nms_pre above %d (IA_E_LIMIT_NMS_PRE)' % 4096,
+           -5: 'max_per_img above %d (IA_E_LIMIT_PER_IMG)' % 1024}
+
+
 def check(rc, what):
     if rc != 0:
-        kind = 'argument error' if rc == -1 else ('workspace too small' if rc == -2 else
-                                                  'hipError_t %d' % rc)
-        raise IouAwareLibraryError('%s failed: %s' % (what, kind))
+        raise IouAwareLibraryError('%s failed: %s' % (what, _ERRORS.get(rc, 'hipError_t %d' % rc)))
