@@ -159,11 +159,9 @@ def decode_stage_roofline(stepper, reps=10, rounds=5):
     shapes = [x['img_shape'] for x in stepper.metas]
     factors = [x['scale_factor'] for x in stepper.metas]
     ws = ops.select_workspace(geom, cls[0].shape[0], cls[0].device)
-
-    def stage():
-        rm = ops.decode_fuse_rowmax(geom, cls, reg, iou, ws)
-        idx = ops.select_topk(geom, rm, ws)
-        return ops.gather_decode(geom, cls, reg, iou, idx, shapes, factors, True)
+    # one C-ABI call per pass (ia_decode_stage: the four launches ia_get_bboxes starts with, in
+    # its workspace) -- the host stays far ahead of the device
+    stage = ops.DecodeStage(geom, cls, reg, iou, shapes, factors, True).run
 
     def rowmax():
         return ops.decode_fuse_rowmax(geom, cls, reg, iou, ws)

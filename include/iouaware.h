@@ -151,8 +151,15 @@ int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch,
                            size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
                            int32_t *num, int32_t *keep_count, int32_t *keep_rows, void *stream);
 
-/* Whole path in one call (what the Python head calls).                        */
+/* Whole path in one call (what the Python head calls).
+ * WORKSPACE CONTRACT of ia_get_bboxes / ia_get_bboxes_lazy / ia_decode_stage: the workspace holds a
+ * few words of state (arrival counters of the fused row-max + top-k-filter launch).  Zero-fill it
+ * ONCE before its first use; every call leaves it ready for the next one.  Do not let anything else
+ * write to it between calls (if something did, zero it again).  ia_get_bboxes_status_offset() is the
+ * byte offset of an int32 status word the launch sets when it finds the contract broken (1: a
+ * filter workgroup timed out waiting, 2: counters above their maximum); 0 = fine.            */
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
+size_t ia_get_bboxes_status_offset(const ia_head_geom *g, int batch);
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                   const float *img_hw, const float *scale_factor, int rescale, float score_thr,
                   float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,
@@ -180,6 +187,13 @@ int ia_multiclass_nms_lazy(const float *boxes, const float *scores_t, const floa
                            int max_per_img, int candidates, void *workspace,
                            size_t workspace_bytes, float *dets, int32_t *labels, int32_t *rows,
                            int32_t *num, void *stream);
+
+/* The decode stage of ia_get_bboxes on its own -- row-max (+ group maxima), top-k, gather / decode
+ * (iou_aware_retina_head.py:499-558; SURVEY 8(d)'s unit) -- in the ia_get_bboxes workspace, where
+ * ia_get_bboxes_workspace_layout finds cand_idx, boxes, scores_t and best_score afterwards.   */
+int ia_decode_stage(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                    const float *img_hw, const float *scale_factor, int rescale, void *workspace,
+                    size_t workspace_bytes, void *stream);
 
 /* Workspace carve-up of ia_get_bboxes (host helper for stage-level tests):
  * byte offsets of rowmax, cand_idx, boxes, scores_t, keep_count, keep_rows,

@@ -272,6 +272,15 @@ size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch)
     return w.total;
 }
 
+size_t ia_get_bboxes_status_offset(const ia_head_geom *g, int batch)
+{
+    ia::WsLayout w;
+    if (ia::ws_layout(g, batch, w)) return 0;
+    ia::LevelTable t;
+    ia::make_level_table(g, t);
+    return w.off[8] + ia::select_workspace_status_offset(t, batch);
+}
+
 int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[8])
 {
     ia::WsLayout w;
@@ -279,6 +288,31 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
     if (rc) return rc;
     for (int i = 0; i < 8; ++i) offsets[i] = w.off[i];
     return 0;
+}
+
+static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                             const float *img_hw, const float *scale_factor, int rescale,
+                             void *workspace, size_t workspace_bytes, hipStream_t s,
+                             ia::WsLayout &w, ia::LevelTable &t)
+{
+    int rc = ia::ws_layout(g, batch, w);
+    if (rc) return rc;
+    if (!p || !workspace) return IA_E_ARG;
+    if (workspace_bytes < w.total) return IA_E_WORKSPACE;
+    if (((uintptr_t)workspace & 255u) != 0) return IA_E_ARG;
+    char *ws = static_cast<char *>(workspace);
+    float *rowmax = reinterpret_cast<float *>(ws + w.off[0]);
+    int32_t *cand = reinterpret_cast<int32_t *>(ws + w.off[1]);
+    float *boxes = reinterpret_cast<float *>(ws + w.off[2]);
+    float *scores_t = reinterpret_cast<float *>(ws + w.off[3]);
+    float *best = reinterpret_cast<float *>(ws + w.off[6]);
+    ia::make_level_table(g, t);
+    ia::BaseAnchors ba;
+    ia::base_from_geom(g, ba);
+    // row-max (+ group maxima) and the top-k's filter in one launch where the layout allows
+    if ((rc = ia::launch_rowmax_select(t, *p, batch, dtype, rowmax, cand, ws + w.off[8], s))) return rc;
+    return ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw, scale_factor,
+                             rescale, boxes, scores_t, best, w.Rs, s);
 }
 
 // lazy_candidates < 0: the complete NMS for every image (keep_count / keep_rows of all classes
@@ -291,32 +325,18 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
                            int32_t *rows, int32_t *num, void *stream)
 {
     ia::WsLayout w;
-    int rc = ia::ws_layout(g, batch, w);
+    ia::LevelTable t;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = decode_stage_impl(g, p, batch, dtype, img_hw, scale_factor, rescale, workspace,
+                               workspace_bytes, s, w, t);
     if (rc) return rc;
-    if (!p || !workspace) return IA_E_ARG;
-    if (workspace_bytes < w.total) return IA_E_WORKSPACE;
-    if (((uintptr_t)workspace & 255u) != 0) return IA_E_ARG;
     char *ws = static_cast<char *>(workspace);
-    float *rowmax = reinterpret_cast<float *>(ws + w.off[0]);
-    int32_t *cand = reinterpret_cast<int32_t *>(ws + w.off[1]);
     float *boxes = reinterpret_cast<float *>(ws + w.off[2]);
     float *scores_t = reinterpret_cast<float *>(ws + w.off[3]);
     int32_t *kc = reinterpret_cast<int32_t *>(ws + w.off[4]);
     int32_t *kr = reinterpret_cast<int32_t *>(ws + w.off[5]);
     float *best = reinterpret_cast<float *>(ws + w.off[6]);
     void *nms_ws = ws + w.off[7];
-    hipStream_t s = (hipStream_t)stream;
-    ia::LevelTable t;
-    ia::make_level_table(g, t);
-    ia::BaseAnchors ba;
-    ia::base_from_geom(g, ba);
-    // the row-max kernel also leaves the group maxima the top-k's filter starts from
-    float *groupmax = ia::select_workspace_groupmax(t, batch, ws + w.off[8]);
-    if ((rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, s, groupmax))) return rc;
-    if ((rc = ia::launch_select(t, rowmax, batch, cand, ws + w.off[8], s, true))) return rc;
-    if ((rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw,
-                                scale_factor, rescale, boxes, scores_t, best, w.Rs, s)))
-        return rc;
     const int32_t *gate = nullptr;
     if (lazy_candidates >= 0) {
         int32_t *need_full = reinterpret_cast<int32_t *>(ws + w.off[10]);
@@ -334,6 +354,16 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
                    (ia::nms_workspace_bytes(batch, w.R, t.C, noff) + 255) / 256 * 256;
     return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, fin_ws,
                                dets, labels, rows, num, s, gate);
+}
+
+int ia_decode_stage(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                    const float *img_hw, const float *scale_factor, int rescale, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    ia::WsLayout w;
+    ia::LevelTable t;
+    return decode_stage_impl(g, p, batch, dtype, img_hw, scale_factor, rescale, workspace,
+                             workspace_bytes, (hipStream_t)stream, w, t);
 }
 
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,

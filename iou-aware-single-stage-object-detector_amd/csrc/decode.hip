@@ -22,9 +22,9 @@
 // fp32 (exhaustively checked by tests/test_oracle_math.py), so the max over
 // classes is taken on the raw logits and the transcendental part runs once
 // per anchor instead of once per class.
-#include <type_traits>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
+#include "ia_rowmax_dev.hpp"
 
 namespace ia {
 
@@ -38,56 +38,7 @@ struct RowmaxArgs {
     // first step of the top-k (select.hip): maxima of groups of consecutive stored scores;
     // groupmax == nullptr: not wanted
     SelPlan plan;
-    float *groupmax;
-};
-
-// max over `lanes` (a power of two) neighbouring lanes, valid in every lane of the group
-__device__ __forceinline__ float lanes_max(float v, int lanes)
-{
-    for (int off = 1; off < lanes; off <<= 1) {
-        const float o = __shfl_xor(v, off);
-        v = (v < o) ? o : v;
-    }
-    return v;
-}
-
-// PPL positions per lane: one 16-byte load per class plane.  The logits are read
-// exactly once, so the loads are non-temporal (no L2 / Infinity-Cache allocation):
-// measured +9 % on the P3 stream (5.37 -> 5.85 TB/s, tools/ubench).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <typename T> struct Lane;
-template <> struct Lane<float> {
-    static constexpr int PPL = 4;
-    static __device__ __forceinline__ void load(const float *p, float (&v)[4])
-    {
-        f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    }
-    static __device__ __forceinline__ void load_cached(const float *p, float (&v)[4])
-    {
-        f32x4 q = *reinterpret_cast<const f32x4 *>(p);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    }
-};
-template <> struct Lane<uint16_t> {
-    static constexpr int PPL = 8;
-    static __device__ __forceinline__ void load(const uint16_t *p, float (&v)[8])
-    {
-        u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-        v[0] = from_bits(q.x << 16); v[1] = from_bits(q.x & 0xffff0000u);
-        v[2] = from_bits(q.y << 16); v[3] = from_bits(q.y & 0xffff0000u);
-        v[4] = from_bits(q.z << 16); v[5] = from_bits(q.z & 0xffff0000u);
-        v[6] = from_bits(q.w << 16); v[7] = from_bits(q.w & 0xffff0000u);
-    }
-    static __device__ __forceinline__ void load_cached(const uint16_t *p, float (&v)[8])
-    {
-        u32x4 q = *reinterpret_cast<const u32x4 *>(p);
-        v[0] = from_bits(q.x << 16); v[1] = from_bits(q.x & 0xffff0000u);
-        v[2] = from_bits(q.y << 16); v[3] = from_bits(q.y & 0xffff0000u);
-        v[4] = from_bits(q.z << 16); v[5] = from_bits(q.z & 0xffff0000u);
-        v[6] = from_bits(q.w << 16); v[7] = from_bits(q.w & 0xffff0000u);
-    }
+    uint32_t *groupmax;                   // ordered keys (bits | 0x80000000), like the channels-last kernel
 };
 
 // One wavefront per (image, level, anchor, tile of 64*PPL positions); tile is the
@@ -169,7 +120,7 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
         if (g) {
             // groups of g consecutive positions of this (image, anchor) plane
             const int gpp = (HW + g - 1) / g;
-            float *gm = a.groupmax + a.plan.goff[l] + ((size_t)b * A + an) * gpp;
+            uint32_t *gm = a.groupmax + a.plan.goff[l] + ((size_t)b * A + an) * gpp;
             if (HW % PPL == 0) {                            // lane = PPL consecutive positions
                 if (g >= PPL) {
                     float v = sc[0];
@@ -177,21 +128,21 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
                     for (int j = 1; j < PPL; ++j) v = (v < sc[j]) ? sc[j] : v;
                     const int lanes = g / PPL;
                     v = lanes_max(v, lanes);
-                    if ((lane & (lanes - 1)) == 0 && pos[0] < HW) gm[pos[0] / g] = v;
+                    if ((lane & (lanes - 1)) == 0 && pos[0] < HW) gm[pos[0] / g] = to_bits(v) | 0x80000000u;
                 } else {                                    // g = 4, PPL = 8: two groups per lane
 #pragma unroll
                     for (int h = 0; h < PPL; h += 4) {
                         float v = sc[h];
 #pragma unroll
                         for (int j = 1; j < 4; ++j) v = (v < sc[h + j]) ? sc[h + j] : v;
-                        if (pos[h] < HW) gm[pos[h] / g] = v;
+                        if (pos[h] < HW) gm[pos[h] / g] = to_bits(v) | 0x80000000u;
                     }
                 }
             } else {                                        // lane = positions p0 + lane + 64 j
 #pragma unroll
                 for (int j = 0; j < PPL; ++j) {
                     const float v = lanes_max(sc[j], g);
-                    if ((lane & (g - 1)) == 0 && pos[j] < HW) gm[pos[j] / g] = v;
+                    if ((lane & (g - 1)) == 0 && pos[j] < HW) gm[pos[j] / g] = to_bits(v) | 0x80000000u;
                 }
             }
         }
@@ -206,102 +157,15 @@ __global__ void __launch_bounds__(64) k_rowmax(RowmaxArgs a)
 // fully coalesced, non-temporal 16-byte loads per lane (1 KiB per instruction); lane maxima
 // are transposed through LDS (row stride VPR+1: conflict-free) so that lane r reduces row r,
 // and the row maxima are stored in row order p*A + a, 256 B per wavefront.
-struct RowmaxNhwcArgs {
-    LevelTable t;
-    ia_level_ptrs p;
-    float *rowmax;
-    int32_t blk_off[IA_MAX_LEVELS + 1];   // prefix of ceil(B * N_l / 64), levels in REVERSE order
-    int32_t batch, anchors_per_img, big_first;
-    SelPlan plan;                         // see RowmaxArgs
-    float *groupmax;
-};
-
-constexpr int kMaxVpr = 32;              // 16-byte vectors per row: C * sizeof(T) <= 512 bytes
-#ifndef IA_ROWMAX_BATCH
-#define IA_ROWMAX_BATCH 20
-#endif
-constexpr int kRowmaxBatch = IA_ROWMAX_BATCH;   // vector loads in flight per lane (tools/ubench/rowmax_bench.hip)
-
 template <typename T, int VPR_T>         // VPR_T = 0: run-time vectors per row
 __global__ void __launch_bounds__(64) k_rowmax_nhwc(RowmaxNhwcArgs a)
 {
-    constexpr int PPL = Lane<T>::PPL;
     __shared__ float s_m[64 * ((VPR_T ? VPR_T : kMaxVpr) + 1)];
-    const int lane = threadIdx.x;
-    const int L = a.t.num_levels;
     int rem = blockIdx.x, rl = 0;
     while (rem >= a.blk_off[rl + 1]) ++rl;
     rem -= a.blk_off[rl];
-    const int l = a.big_first ? rl : L - 1 - rl;
-    const int vpr = VPR_T ? VPR_T : a.t.C / PPL;
-    const int n_l = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
-    const int64_t rows = (int64_t)a.batch * n_l;
-    const int64_t r0 = (int64_t)rem * 64;
-    const int nrow = (rows - r0 < 64) ? (int)(rows - r0) : 64;
-    const int nvec = nrow * vpr;
-    const T *src = static_cast<const T *>(a.p.cls[l]) + r0 * a.t.C;
-    // this lane's row: its IoU logit is requested first so that its latency hides behind the
-    // class loads instead of following the barrier
-    const int64_t g = r0 + ((lane < nrow) ? lane : (nrow - 1));
-    const float il = load_f32<T>(static_cast<const T *>(a.p.iou[l]) + g);
-    // All loads of a batch are issued before the first one is consumed: written as one loop
-    // (load, reduce, LDS store per vector) the compiler waits for each load before issuing the
-    // next -- ONE kilobyte in flight per wavefront, a latency-bound kernel that only its 29
-    // wavefronts per CU kept near 6 TB/s.
-    auto batch = [&](int k0, auto nb_tag) {
-        constexpr int NB = decltype(nb_tag)::value;
-        float v[NB][PPL];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int f = (k0 + u) * 64 + lane;
-            const int fc = (f < nvec) ? f : (nvec - 1);         // loads are never predicated
-            Lane<T>::load(src + (size_t)fc * PPL, v[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int f = (k0 + u) * 64 + lane;
-            float m = v[u][0];
-#pragma unroll
-            for (int j = 1; j < PPL; ++j) m = (m < v[u][j]) ? v[u][j] : m;
-            const int row = f / vpr, c4 = f - row * vpr;
-            if (f < nvec) s_m[row * (vpr + 1) + c4] = m;
-        }
-    };
-    if (VPR_T) {
-        constexpr int NB = (VPR_T % kRowmaxBatch == 0) ? kRowmaxBatch : (VPR_T ? VPR_T : 1);
-#pragma unroll
-        for (int k = 0; k < VPR_T; k += NB) batch(k, std::integral_constant<int, NB>());
-    } else {
-        int k = 0;
-        for (; k + 4 <= vpr; k += 4) batch(k, std::integral_constant<int, 4>());
-        for (; k < vpr; ++k) batch(k, std::integral_constant<int, 1>());
-    }
-    __syncthreads();
-    float score = 0.0f;                                     // scores are >= 0
-    if (lane < nrow) {
-        const float *sr = s_m + lane * (vpr + 1);
-        float m = sr[0];
-        for (int c4 = 1; c4 < vpr; ++c4) m = (m < sr[c4]) ? sr[c4] : m;
-        const int b = (int)(g / n_l);
-        const int i = (int)(g - (int64_t)b * n_l);
-#ifdef IA_ROWMAX_NOMATH                                      /* tools/ubench/rowmax_bench.hip only */
-        score = m * il;
-#else
-        score = sqrt_sigmoidf_(m) * sqrt_sigmoidf_(il);
-#endif
-        a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] = score;
-    }
-    if (a.groupmax) {
-        // maxima of groups of grp consecutive rows of this level's flat (B * N_l) row space;
-        // r0 is a multiple of 64, so the groups are lane-aligned (a group that straddles two
-        // images is written like any other and left out by the reader)
-        const int grp = a.plan.grp[l];
-        if (grp) {
-            const float v = lanes_max(score, grp);
-            if ((lane & (grp - 1)) == 0 && lane < nrow)
-                a.groupmax[a.plan.goff[l] + (r0 + lane) / grp] = v;
-        }
-    }
+    const int l = a.big_first ? rl : a.t.num_levels - 1 - rl;
+    rowmax_nhwc_wave<T, VPR_T, false>(a, l, rem, s_m, (int)threadIdx.x);
 }
 
 // unused dynamic LDS per workgroup = an occupancy cap for the streaming kernel (tools/ubench/
@@ -317,7 +181,7 @@ static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int b
     RowmaxNhwcArgs a;
     a.t = t; a.p = p; a.rowmax = rowmax; a.batch = batch;
     a.anchors_per_img = t.anchor_off[t.num_levels];
-    a.groupmax = groupmax;
+    a.groupmax = reinterpret_cast<uint32_t *>(groupmax);
     int prc = make_sel_plan(t, batch, a.plan);
     if (prc) return prc;
     a.blk_off[0] = 0;
@@ -355,7 +219,7 @@ int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dt
     const int tile = 64 * (dtype == IA_F32 ? Lane<float>::PPL : Lane<uint16_t>::PPL);
     RowmaxArgs a;
     a.t = t; a.p = p; a.rowmax = rowmax;
-    a.groupmax = groupmax;
+    a.groupmax = reinterpret_cast<uint32_t *>(groupmax);
     int prc = make_sel_plan(t, batch, a.plan);
     if (prc) return prc;
     a.blk_off[0] = 0;

@@ -106,10 +106,18 @@ int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dt
 size_t select_workspace_bytes(const LevelTable &t, int batch);
 // where launch_rowmax has to put the group maxima inside the select workspace
 float *select_workspace_groupmax(const LevelTable &t, int batch, void *workspace);
+// byte offset (inside the select workspace) of the fused launch's status word: 0 = fine,
+// 1 = a filter workgroup gave up waiting, 2 = arrival counters found above their maximum
+size_t select_workspace_status_offset(const LevelTable &t, int batch);
 // have_groups: the row-max kernel already filled the workspace's group maxima; otherwise an
 // extra pass over the row-max array derives them first
 int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
                   void *workspace, hipStream_t s, bool have_groups = false);
+// row-max + top-k the way ia_get_bboxes chains them; channels-last heads: row-max and the top-k
+// filter in ONE launch (select.hip, k_rowmax_filter_nhwc).  The select workspace must have been
+// zeroed once by its owner.
+int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
+                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s);
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,

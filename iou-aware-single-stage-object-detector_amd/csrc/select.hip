@@ -32,11 +32,13 @@
 // Levels with N_l <= nms_pre keep their natural order (the reference skips topk there, :537).
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
+#include "ia_rowmax_dev.hpp"
 
 // phase timestamps for tools/ubench/select_bench.hip (compiled out of the library)
 #ifdef IA_SEL_PROFILE
 namespace ia { __device__ unsigned long long g_sel_prof[2][IA_MAX_LEVELS][24];
-               __device__ unsigned long long g_sel_blk[2][16][64][2]; }   // per-block start / end
+               __device__ unsigned long long g_sel_blk[2][16][64][2];     // per-block start / end
+               __device__ unsigned long long g_blk_t[8192][3]; }          // fused launch, per workgroup: start, end, wait end
 #define SEL_PROF(kern, lvl, i)                                                        \
     do { if (blockIdx.y == 0 && threadIdx.x == 0) ia::g_sel_prof[kern][lvl][i] = wall_clock64(); } while (0)
 #define IA_BLOCK_PROF(i) SEL_PROF(1, blockIdx.x, i)
@@ -58,8 +60,9 @@ struct SelArgs {
     LevelTable t;
     SelPlan plan;
     const float *rowmax;
-    const float *groupmax;
+    const uint32_t *groupmax;              // group maxima as ordered keys (never 0)
     int32_t *cand_idx;
+    uint64_t *seg_v;                       // (B, L): {1, threshold key} once a segment's leader has it
     uint32_t *chunk_count;                 // (B, chunks): candidates each filter workgroup kept
     uint64_t *cand;                        // (B, N): candidate keys; chunk c of segment (b, l) owns
                                            // [b * N + anchor_off[l] + c * kSelChunk, + kSelChunk)
@@ -115,16 +118,16 @@ __device__ __forceinline__ int bin_shift(uint32_t range)
 
 struct SegRef { int l, b; uint32_t n, k, beg, cnt, chunk; const float *src; bool natural; uint32_t HW, A; };
 
-__device__ __forceinline__ SegRef locate_chunk(const SelArgs &a)
+__device__ __forceinline__ SegRef locate_chunk(const SelArgs &a, int cx, int b)
 {
     SegRef r;
-    r.b = blockIdx.y;
+    r.b = b;
     int l = 0;
-    while ((int)blockIdx.x >= a.plan.chunk_off[l + 1]) ++l;
+    while (cx >= a.plan.chunk_off[l + 1]) ++l;
     r.l = l;
     r.n = (uint32_t)(a.t.anchor_off[l + 1] - a.t.anchor_off[l]);
     r.k = (uint32_t)(a.t.cand_off[l + 1] - a.t.cand_off[l]);
-    r.chunk = (uint32_t)(blockIdx.x - a.plan.chunk_off[l]);
+    r.chunk = (uint32_t)(cx - a.plan.chunk_off[l]);
     r.beg = r.chunk * kSelChunk;
     r.cnt = (r.n - r.beg < (uint32_t)kSelChunk) ? (r.n - r.beg) : (uint32_t)kSelChunk;
     r.src = a.rowmax + (size_t)r.b * a.anchors_per_img + a.t.anchor_off[l];
@@ -153,7 +156,7 @@ __device__ __forceinline__ void segment_groups(const LevelTable &t, int l, int b
 
 // Fallback producer of the group maxima (the stage-wise C-ABI, where the row-max array comes from
 // the caller): one thread per group over the stored scores.
-__global__ void __launch_bounds__(256) k_sel_groupmax(SelArgs a, float *groupmax)
+__global__ void __launch_bounds__(256) k_sel_groupmax(SelArgs a, uint32_t *groupmax)
 {
     const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int l = 0;
@@ -183,24 +186,79 @@ __global__ void __launch_bounds__(256) k_sel_groupmax(SelArgs a, float *groupmax
             m = (m < src[pos]) ? src[pos] : m;
         }
     }
-    groupmax[gid0] = m;
+    groupmax[gid0] = ordered_key(m);                 // m >= +0: bits | 0x80000000
 }
 
-__global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
+// v: a lower bound of segment r's k-th largest key from (a sample of) its group maxima -- ONE
+// histogram pass over 2048 linear bins between their minimum and maximum, v = the lower edge of the
+// bin where the count from the top reaches k.  s_hist must be zero on entry (and a barrier later).
+__device__ __forceinline__ uint32_t segment_threshold(const SelArgs &a, const SegRef &r, uint32_t *s_hist,
+                                                      uint32_t *s_misc)
 {
-    __shared__ uint32_t s_hist[kBins];
-    __shared__ uint32_t s_misc[24];
-    const SegRef r = locate_chunk(a);
+    const int tid = threadIdx.x;
+    const int g = a.plan.grp[r.l];
+    int64_t first, count;
+    segment_groups(a.t, r.l, r.b, g, first, count);
+    const uint32_t stride = (uint32_t)((count + kMaxGroups - 1) >> 12);        // kMaxGroups = 4096
+    const uint32_t used = count > 0 ? ((uint32_t)count + stride - 1) / stride : 0u;
+    if (used < r.k) {                                    // uniform: too few groups, no filtering
+        __syncthreads();
+        return 0u;
+    }
+    const uint32_t *gm = a.groupmax + a.plan.goff[r.l] + first;
+    uint32_t gk[kGroupsPerThread];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int u = 0; u < kGroupsPerThread; ++u) {
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+        gk[u] = gm[(size_t)(j < used ? j : used - 1) * stride];    // never predicated
+    }
+#pragma unroll
+    for (int u = 0; u < kGroupsPerThread; ++u) {
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+        if (j < used) { lo = gk[u] < lo ? gk[u] : lo; hi = gk[u] > hi ? gk[u] : hi; }
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off), h2 = (uint32_t)__shfl_xor((int)hi, off);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & 63) == 0) { s_misc[8 + (tid >> 6)] = lo; s_misc[12 + (tid >> 6)] = hi; }
+    __syncthreads();                                     // also: s_hist cleared
+#pragma unroll
+    for (int w = 0; w < kFilterThreads / kWave; ++w) {
+        lo = s_misc[8 + w] < lo ? s_misc[8 + w] : lo;
+        hi = s_misc[12 + w] > hi ? s_misc[12 + w] : hi;
+    }
+    const int shift = bin_shift(hi - lo);
+#pragma unroll
+    for (int u = 0; u < kGroupsPerThread; ++u) {
+        const uint32_t j = (uint32_t)u * kFilterThreads + tid;
+        if (j < used) atomicAdd(&s_hist[(gk[u] - lo) >> shift], 1u);
+    }
+    __syncthreads();
+    int d; uint32_t above, in_d;
+    find_bin_256(s_hist, r.k, s_misc, d, above, in_d);
+    return lo + ((uint32_t)d << shift);                  // >= k group maxima are >= v
+}
+
+// One filter workgroup: the scores >= v of its chunk -> the chunk's slice of the candidate list.
+// have_v: the threshold is given (a follower of the fused launch); else derived here.
+__device__ __forceinline__ void sel_filter_body(const SelArgs &a, const SegRef &r, uint32_t *s_hist,
+                                                uint32_t *s_misc /* 24 words */, bool have_v = false,
+                                                uint32_t v_given = 0)
+{
     const int tid = threadIdx.x;
 #ifdef IA_SEL_PROFILE
-    const bool prof = (int)blockIdx.x == a.plan.chunk_off[r.l];
+    const bool prof = r.chunk == 0 && r.b == 0;
 #define FPROF(i) do { if (prof) SEL_PROF(0, r.l, i); } while (0)
 #else
 #define FPROF(i) do { } while (0)
 #endif
     FPROF(0);
 #ifdef IA_SEL_PROFILE
-    if (tid == 0 && blockIdx.y < 16 && blockIdx.x < 64) g_sel_blk[0][blockIdx.y][blockIdx.x][0] = wall_clock64();
+    const int pcx = a.plan.chunk_off[r.l] + (int)r.chunk;
+    if (tid == 0 && r.b < 16 && pcx < 64) g_sel_blk[0][r.b][pcx][0] = wall_clock64();
 #endif
     // this chunk's scores: requested first, their latency hides behind the threshold search
     constexpr int U = kSelChunk / kFilterThreads;       // 16 scores per thread
@@ -213,59 +271,16 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
         kf[u] = r.src[r.beg + (j < r.cnt ? j : r.cnt - 1)];
     }
     // ---- v: a lower bound of the segment's k-th largest key from (a sample of) its group maxima
-    const int g = a.plan.grp[r.l];
-    int64_t first, count;
-    segment_groups(a.t, r.l, r.b, g, first, count);
-    const uint32_t stride = (uint32_t)((count + kMaxGroups - 1) >> 12);        // kMaxGroups = 4096
-    const uint32_t used = count > 0 ? ((uint32_t)count + stride - 1) / stride : 0u;
     for (int i = tid; i < kBins; i += kFilterThreads) s_hist[i] = 0;
     if (tid == 0) s_misc[16] = 0;                        // candidates of this chunk
     uint32_t v = 0;
-    if (used >= r.k) {                                   // uniform
-        const float *gm = a.groupmax + a.plan.goff[r.l] + first;
-        float gf[kGroupsPerThread];
-        uint32_t gk[kGroupsPerThread];
-        uint32_t lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-        for (int u = 0; u < kGroupsPerThread; ++u) {
-            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
-            gf[u] = gm[(size_t)(j < used ? j : used - 1) * stride];
-        }
-#pragma unroll
-        for (int u = 0; u < kGroupsPerThread; ++u) gk[u] = ordered_key(gf[u]);
-        FPROF(1);
-#pragma unroll
-        for (int u = 0; u < kGroupsPerThread; ++u) {
-            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
-            if (j < used) { lo = gk[u] < lo ? gk[u] : lo; hi = gk[u] > hi ? gk[u] : hi; }
-        }
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off), h2 = (uint32_t)__shfl_xor((int)hi, off);
-            lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
-        }
-        if ((tid & 63) == 0) { s_misc[8 + (tid >> 6)] = lo; s_misc[12 + (tid >> 6)] = hi; }
-        __syncthreads();                                 // also: s_hist cleared
-#pragma unroll
-        for (int w = 0; w < kFilterThreads / kWave; ++w) {
-            lo = s_misc[8 + w] < lo ? s_misc[8 + w] : lo;
-            hi = s_misc[12 + w] > hi ? s_misc[12 + w] : hi;
-        }
-        const int shift = bin_shift(hi - lo);
-#pragma unroll
-        for (int u = 0; u < kGroupsPerThread; ++u) {
-            const uint32_t j = (uint32_t)u * kFilterThreads + tid;
-            if (j < used) atomicAdd(&s_hist[(gk[u] - lo) >> shift], 1u);
-        }
+    if (have_v) {
+        v = v_given;
         __syncthreads();
-        FPROF(2);
-        int d; uint32_t above, in_d;
-        find_bin_256(s_hist, r.k, s_misc, d, above, in_d);
-        v = lo + ((uint32_t)d << shift);                 // >= k group maxima are >= v
-        FPROF(3);
     } else {
-        __syncthreads();
+        v = segment_threshold(a, r, s_hist, s_misc);
     }
+    FPROF(3);
     uint32_t key[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) key[u] = ordered_key(kf[u]);
@@ -296,7 +311,123 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
         a.chunk_count[(size_t)r.b * a.total_chunks + a.plan.chunk_off[r.l] + r.chunk] = s_misc[16];
     FPROF(5);
 #ifdef IA_SEL_PROFILE
-    if (tid == 0 && blockIdx.y < 16 && blockIdx.x < 64) g_sel_blk[0][blockIdx.y][blockIdx.x][1] = wall_clock64();
+    if (tid == 0 && r.b < 16 && pcx < 64) g_sel_blk[0][r.b][pcx][1] = wall_clock64();
+#endif
+}
+
+__global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
+{
+    __shared__ uint32_t s_hist[kBins];
+    __shared__ uint32_t s_misc[24];
+    sel_filter_body(a, locate_chunk(a, (int)blockIdx.x, (int)blockIdx.y), s_hist, s_misc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-max AND filter in ONE launch (channels-last heads; ia_get_bboxes / ia_decode_stage).
+// Workgroup order: per level, first its row-max workgroups (four wavefronts of 64 rows each,
+// ia_rowmax_dev.hpp, PUBLISH form), then -- for a filtered level -- its filter workgroups, so
+// that a level's filtering runs under the NEXT levels' streaming and the dependent launch with
+// its ramp (8-10 us) leaves the critical path.
+//   producer  a row-max wavefront writes its scores with write-through stores, drains its memory
+//             counter, and only then stores its group maxima: non-zero words (ordered keys);
+//   leader    the filter workgroup of a segment's chunk 0 re-reads the segment's group words
+//             (agent-scope relaxed loads) until none is zero -- every 64-row unit of the segment
+//             is then in memory --, does ONE agent acquire, derives the threshold v and publishes
+//             the granule {1, v} for the segment;
+//   follower  the other chunks' workgroups poll that one granule (one lane), acquire, filter.
+// No atomics, no counters (2 362 wavefronts arriving on one device-scope counter serialised into
+// 120 us).  State: the group words and granules must be ZERO when the launch starts; k_sel_final,
+// always launched behind this kernel, clears them again (include/iouaware.h: WORKSPACE CONTRACT).
+// Residency: the filter workgroups (chunks x batch, 4 wavefronts each) can never fill the chip,
+// so a row-max workgroup always finds a slot whatever the dispatch order: no deadlock.  Spins are
+// bounded; a timeout leaves a non-zero status word in the workspace.
+constexpr uint32_t kSpinLimit = 1u << 21;
+
+struct FusedOrder {
+    int32_t item_off[2 * IA_MAX_LEVELS + 1];    // prefix of workgroups: level l's row-max, level l's filter
+    int32_t units[IA_MAX_LEVELS];               // 64-row units of level l
+};
+
+template <typename T, int VPR_T>
+__global__ void __launch_bounds__(kFilterThreads, 4) k_rowmax_filter_nhwc(RowmaxNhwcArgs ra, SelArgs sa,
+                                                                       FusedOrder fo)
+{
+    constexpr int kTile = 64 * ((VPR_T ? VPR_T : kMaxVpr) + 1);
+    constexpr int kLdsWords = (4 * kTile > kBins + 24) ? 4 * kTile : (kBins + 24);
+    __shared__ uint32_t s_raw[kLdsWords];
+    int it = 0;
+    while ((int)blockIdx.x >= fo.item_off[it + 1]) ++it;
+    const int l = it >> 1, local = (int)blockIdx.x - fo.item_off[it];
+    if ((it & 1) == 0) {
+        const int wv = threadIdx.x >> 6;
+        const int unit = local * 4 + wv;
+#ifdef IA_SEL_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk_t[blockIdx.x][0] = wall_clock64();
+#endif
+        if (unit < fo.units[l])
+            rowmax_nhwc_wave<T, VPR_T, true>(ra, l, unit, reinterpret_cast<float *>(s_raw) + wv * kTile,
+                                             (int)(threadIdx.x & 63));
+#ifdef IA_SEL_PROFILE
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_blk_t[blockIdx.x][1] = wall_clock64();
+#endif
+        return;
+    }
+#ifdef IA_ABL_NO_FILTER                                      /* tools/ubench/stage_bench.hip only */
+    return;
+#endif
+    const int nch = sa.plan.chunk_off[l + 1] - sa.plan.chunk_off[l];
+    const int b = local / nch, cx = sa.plan.chunk_off[l] + (local - b * nch);
+    const SegRef r = locate_chunk(sa, cx, b);
+    uint32_t *s_hist = s_raw, *s_misc = s_raw + kBins;
+    uint64_t *granule = sa.seg_v + (size_t)b * sa.t.num_levels + l;
+    uint32_t *status = sa.chunk_count + (size_t)sa.batch * sa.total_chunks;
+    const int tid = threadIdx.x;
+#ifdef IA_SEL_PROFILE
+    if (tid == 0 && blockIdx.x < 8192) g_blk_t[blockIdx.x][0] = wall_clock64();
+#endif
+    uint32_t v;
+    if (r.chunk == 0) {
+        // leader: every group word of the segment, the image-straddling ones included
+        const int g = sa.plan.grp[l];
+        const int lg = 31 - __builtin_clz((unsigned)g);
+        const int64_t g0 = ((int64_t)b * r.n) >> lg, g1 = (((int64_t)(b + 1) * r.n - 1) >> lg) + 1;
+        const uint32_t *gw = sa.groupmax + sa.plan.goff[l];
+        for (uint32_t spins = 0;; ++spins) {
+            int ok = 1;
+            for (int64_t j = g0 + tid; j < g1; j += kFilterThreads)
+                ok &= __hip_atomic_load(gw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (__syncthreads_and(ok)) break;
+            if (spins > kSpinLimit) { if (tid == 0) *status = 1u; break; }      // uniform
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int i = tid; i < kBins; i += kFilterThreads) s_hist[i] = 0;
+        __syncthreads();
+        v = segment_threshold(sa, r, s_hist, s_misc);
+        if (tid == 0)
+            __hip_atomic_store(granule, (1ull << 32) | (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                    // s_hist / s_misc are reused below
+    } else {
+        if (tid == 0) {
+            uint64_t x;
+            uint32_t spins = 0;
+            while (((x = __hip_atomic_load(granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > kSpinLimit) { *status = 1u; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_misc[20] = (uint32_t)x;
+        }
+        __syncthreads();
+        v = s_misc[20];
+        __syncthreads();
+    }
+#ifdef IA_SEL_PROFILE
+    if (tid == 0 && blockIdx.x < 8192) g_blk_t[blockIdx.x][2] = wall_clock64();
+#endif
+    sel_filter_body(sa, r, s_hist, s_misc, true, v);
+#ifdef IA_SEL_PROFILE
+    if (tid == 0 && blockIdx.x < 8192) g_blk_t[blockIdx.x][1] = wall_clock64();
 #endif
 }
 
@@ -315,6 +446,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
     const int l = blockIdx.x, b = blockIdx.y;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     SEL_PROF(1, l, 0);
+
     const uint32_t n = (uint32_t)(a.t.anchor_off[l + 1] - a.t.anchor_off[l]);
     const uint32_t k = (uint32_t)(a.t.cand_off[l + 1] - a.t.cand_off[l]);
     int32_t *out = a.cand_idx + (size_t)b * a.cands_per_img + a.t.cand_off[l];
@@ -323,6 +455,15 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
         return;
     }
     const bool filtered = a.plan.grp[l] != 0;
+    if (filtered && a.t.layout == IA_LAYOUT_NHWC) {
+        // state of the fused launch (k_rowmax_filter_nhwc) back to zero: the segment's group words
+        // -- the straddling ones too -- and its granule; nobody reads them any more in this call
+        const int lg = 31 - __builtin_clz((unsigned)a.plan.grp[l]);
+        const int64_t g0 = ((int64_t)b * n) >> lg, g1 = (((int64_t)(b + 1) * n - 1) >> lg) + 1;
+        uint32_t *gw = const_cast<uint32_t *>(a.groupmax) + a.plan.goff[l];
+        for (int64_t j = g0 + tid; j < g1; j += nt) gw[j] = 0u;
+        if (tid == 0) a.seg_v[(size_t)b * a.t.num_levels + l] = 0ull;
+    }
     const float *src = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
     const uint64_t *list = a.cand + (size_t)b * a.anchors_per_img + a.t.anchor_off[l];
     const bool natural = a.t.layout == IA_LAYOUT_NHWC;
@@ -484,7 +625,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
     SEL_PROF(1, l, 15);
 }
 
-struct SelLayout { size_t chunk_count, groupmax, cand, total; };
+struct SelLayout { size_t seg_v, chunk_count, groupmax, cand, total; };
 
 static SelLayout layout(const LevelTable &t, const SelPlan &p, int batch)
 {
@@ -492,8 +633,10 @@ static SelLayout layout(const LevelTable &t, const SelPlan &p, int batch)
     SelLayout w;
     const size_t B = (size_t)batch;
     size_t o = 0;
-    w.chunk_count = o; o = up(o + B * (size_t)p.chunk_off[IA_MAX_LEVELS] * sizeof(uint32_t));
-    w.groupmax = o; o = up(o + (size_t)p.goff[IA_MAX_LEVELS] * sizeof(float));
+    w.seg_v = o; o = up(o + B * (size_t)t.num_levels * sizeof(uint64_t));
+    // (+1: status word of the fused launch's bounded spin)
+    w.chunk_count = o; o = up(o + (B * (size_t)p.chunk_off[IA_MAX_LEVELS] + 1) * sizeof(uint32_t));
+    w.groupmax = o; o = up(o + (size_t)p.goff[IA_MAX_LEVELS] * sizeof(uint32_t));
     w.cand = o;
     if (p.chunk_off[IA_MAX_LEVELS] > 0)
         o = up(o + B * (size_t)t.anchor_off[t.num_levels] * sizeof(uint64_t));
@@ -508,26 +651,35 @@ size_t select_workspace_bytes(const LevelTable &t, int batch)
     return layout(t, p, batch).total;
 }
 
+size_t select_workspace_status_offset(const LevelTable &t, int batch)
+{
+    SelPlan p;
+    if (make_sel_plan(t, batch, p)) return 0;
+    return layout(t, p, batch).chunk_count +
+           (size_t)batch * (size_t)p.chunk_off[IA_MAX_LEVELS] * sizeof(uint32_t);
+}
+
 float *select_workspace_groupmax(const LevelTable &t, int batch, void *workspace)
 {
+    // (the words are ordered keys, written by the row-max kernels; float * only in the signature)
     SelPlan p;
     if (make_sel_plan(t, batch, p)) return nullptr;
     return reinterpret_cast<float *>(static_cast<char *>(workspace) + layout(t, p, batch).groupmax);
 }
 
-int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
-                  void *workspace, hipStream_t s, bool have_groups)
+// common part of the launchers: argument block, LDS size of the final kernel
+static int prepare_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
+                          void *workspace, SelArgs &a, uint32_t &p_max, size_t &dyn)
 {
     if (batch < 1 || !rowmax || !cand_idx || !workspace) return IA_E_ARG;
-    SelArgs a;
     a.t = t; a.rowmax = rowmax; a.cand_idx = cand_idx; a.batch = batch;
     int rc = make_sel_plan(t, batch, a.plan);
     if (rc) return rc;
     const SelLayout w = layout(t, a.plan, batch);
     char *ws = static_cast<char *>(workspace);
-    float *groupmax = reinterpret_cast<float *>(ws + w.groupmax);
-    a.groupmax = groupmax;
+    a.groupmax = reinterpret_cast<uint32_t *>(ws + w.groupmax);
     a.chunk_count = reinterpret_cast<uint32_t *>(ws + w.chunk_count);
+    a.seg_v = reinterpret_cast<uint64_t *>(ws + w.seg_v);
     a.cand = reinterpret_cast<uint64_t *>(ws + w.cand);
     a.anchors_per_img = t.anchor_off[t.num_levels];
     a.cands_per_img = t.cand_off[t.num_levels];
@@ -540,10 +692,10 @@ int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *
         if (k < n && k > kmax) kmax = k;
         if (a.plan.chunk_off[l + 1] - a.plan.chunk_off[l] > kMaxSegChunks) return IA_E_ARG;
     }
-    uint32_t p_max = 1;
+    p_max = 1;
     while (p_max < kmax) p_max <<= 1;
     a.lds_cap = kSelDenseMax;
-    const size_t dyn = ((size_t)p_max + kBucketCap + (size_t)a.lds_cap) * sizeof(uint64_t);
+    dyn = ((size_t)p_max + kBucketCap + (size_t)a.lds_cap) * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         // up to 32 KiB (sel, k <= 4096) + 96 KiB (stage) + the static scratch: above the 64 KiB a
@@ -554,16 +706,90 @@ int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    return 0;
+}
+
+int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *cand_idx,
+                  void *workspace, hipStream_t s, bool have_groups)
+{
+    SelArgs a;
+    uint32_t p_max;
+    size_t dyn;
+    int rc = prepare_select(t, rowmax, batch, cand_idx, workspace, a, p_max, dyn);
+    if (rc) return rc;
     const int chunks = a.total_chunks;
     if (chunks > 0) {
         if (!have_groups)
             hipLaunchKernelGGL(k_sel_groupmax, dim3((unsigned)((a.plan.goff[IA_MAX_LEVELS] + 255) / 256)),
-                               dim3(256), 0, s, a, groupmax);
+                               dim3(256), 0, s, a, const_cast<uint32_t *>(a.groupmax));
         hipLaunchKernelGGL(k_sel_filter, dim3((unsigned)chunks, (unsigned)batch),
                            dim3(kFilterThreads), 0, s, a);
         rc = hip_status(hipGetLastError());
         if (rc) return rc;
     }
+    hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
+                       dim3(kFinalThreads), dyn, s, a, p_max);
+    return hip_status(hipGetLastError());
+}
+
+// ia_get_bboxes / ia_decode_stage: row-max + top-k.  Channels-last heads with filtered levels take
+// the fused launch (k_rowmax_filter_nhwc) + k_sel_final; everything else the separate kernels.
+// `workspace` (select workspace) must have been zeroed once by its owner (seg_done).
+int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
+                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s)
+{
+    SelArgs a;
+    uint32_t p_max;
+    size_t dyn;
+    int rc = prepare_select(t, rowmax, batch, cand_idx, workspace, a, p_max, dyn);
+    if (rc) return rc;
+    if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
+    bool fused = t.layout == IA_LAYOUT_NHWC && a.total_chunks > 0 && t.C % ppl == 0 && t.C / ppl <= kMaxVpr;
+    for (int l = 0; l < t.num_levels && fused; ++l) fused = (((uintptr_t)p.cls[l] & 15u) == 0);
+    RowmaxNhwcArgs ra;
+    FusedOrder fo;
+    int64_t blocks = 0;
+    if (fused) {
+        ra.t = t; ra.p = p; ra.rowmax = rowmax; ra.batch = batch;
+        ra.anchors_per_img = t.anchor_off[t.num_levels];
+        ra.plan = a.plan; ra.groupmax = const_cast<uint32_t *>(a.groupmax);
+        ra.big_first = 1;
+        for (int i = 0; i <= IA_MAX_LEVELS; ++i) ra.blk_off[i] = 0;        // unused by the fused kernel
+        fo.item_off[0] = 0;
+        for (int l = 0; l < IA_MAX_LEVELS; ++l) {
+            int64_t units = 0, nf = 0;
+            if (l < t.num_levels) {
+                units = ((int64_t)batch * (t.anchor_off[l + 1] - t.anchor_off[l]) + 63) / 64;
+                nf = (int64_t)(a.plan.chunk_off[l + 1] - a.plan.chunk_off[l]) * batch;
+            }
+            if (units > 2147483647LL) return IA_E_ARG;
+            fo.units[l] = (int32_t)units;
+            blocks += (units + 3) / 4;
+            if (blocks > 2147483647LL) return IA_E_ARG;
+            fo.item_off[2 * l + 1] = (int32_t)blocks;
+            blocks += nf;
+            if (blocks > 2147483647LL) return IA_E_ARG;
+            fo.item_off[2 * l + 2] = (int32_t)blocks;
+        }
+    }
+    if (!fused) {
+        rc = launch_rowmax(t, p, batch, dtype, rowmax, s,
+                           reinterpret_cast<float *>(const_cast<uint32_t *>(a.groupmax)));
+        if (rc) return rc;
+        return launch_select(t, rowmax, batch, cand_idx, workspace, s, true);
+    }
+    const dim3 grid((unsigned)blocks), block(kFilterThreads);
+    const int vpr = t.C / ppl;
+    if (dtype == IA_F32) {
+        if (vpr == 20) hipLaunchKernelGGL((k_rowmax_filter_nhwc<float, 20>), grid, block, 0, s, ra, a, fo);
+        else hipLaunchKernelGGL((k_rowmax_filter_nhwc<float, 0>), grid, block, 0, s, ra, a, fo);
+    } else {
+        if (vpr == 10) hipLaunchKernelGGL((k_rowmax_filter_nhwc<uint16_t, 10>), grid, block, 0, s, ra, a, fo);
+        else hipLaunchKernelGGL((k_rowmax_filter_nhwc<uint16_t, 0>), grid, block, 0, s, ra, a, fo);
+    }
+    rc = hip_status(hipGetLastError());
+    if (rc) return rc;
     hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
                        dim3(kFinalThreads), dyn, s, a, p_max);
     return hip_status(hipGetLastError());

@@ -80,6 +80,8 @@ SIGNATURES = {
     'ia_select_topk': (_i, [_G, _vp, _i, _vp, _vp, _sz, _vp]),
     'ia_decode_fuse_rowmax_grouped': (_i, [_G, _P, _i, _i, _vp, _vp, _sz, _vp]),
     'ia_select_topk_grouped': (_i, [_G, _vp, _i, _vp, _vp, _sz, _vp]),
+    'ia_decode_stage': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    'ia_get_bboxes_status_offset': (_sz, [_G, _i]),
     'ia_gather_decode': (_i, [_G, _P, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'ia_multiclass_nms_workspace_bytes': (_sz, [_i, _i, _i]),
     'ia_multiclass_nms': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp, _vp, _vp,

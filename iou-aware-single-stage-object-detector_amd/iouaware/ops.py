@@ -70,6 +70,8 @@ class HeadGeometry(object):
         self.level_cands = [min(nms_pre, n_) if nms_pre > 0 else n_ for n_ in self.level_anchors]
         self.layout = _lib.IA_LAYOUT_NCHW
         self._twin = None
+        # what the workspace carve-up depends on (besides batch, layout and dtype)
+        self.key = (tuple(self.featmap_sizes), A, int(num_classes), int(nms_pre))
 
     def ref(self):
         return C.byref(self.struct)
@@ -155,6 +157,30 @@ def _workspace(device, nbytes):
     return ws
 
 
+_state_ws_cache = {}
+
+
+def _state_workspace(device, nbytes, layout_key):
+    """The workspace of ia_get_bboxes / ia_decode_stage carries state between calls (the flag words
+    of the fused row-max + filter launch: include/iouaware.h, WORKSPACE CONTRACT): its own buffer
+    per (device, stream, geometry, batch) -- the carve-up depends on those --, zero-filled when
+    created, shared with nothing else."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, layout_key, int(nbytes))
+    ws = _state_ws_cache.get(key)
+    if ws is None:
+        if len(_state_ws_cache) >= 16:
+            _state_ws_cache.clear()
+        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _state_ws_cache[key] = ws
+    return ws
+
+
+def get_bboxes_status(geom, batch, ws):
+    """status word of the last fused launch in `ws` (0 = fine): a host synchronisation, tests only"""
+    off = _lib.lib().ia_get_bboxes_status_offset(geom.ref(), int(batch))
+    return int(ws[off:off + 4].view(torch.int32).item())
+
+
 _meta_cache = {}
 
 
@@ -211,7 +237,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     nbytes = L.ia_get_bboxes_workspace_bytes(geom.ref(), B)
     if nbytes == 0:
         raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_get_bboxes')
-    ws = _workspace(dev, nbytes)
+    ws = _state_workspace(dev, nbytes, (geom.key, geom.layout, B, dt))
     hw, sf = _meta_tensors(img_shapes, scale_factors, dev)
     dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
     labels = torch.empty((B, max_per_img), dtype=torch.int32, device=dev)
@@ -229,6 +255,9 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     _lib.check(rc, 'ia_get_bboxes')
     if not debug:
         return dets, labels, rows, num
+    status = get_bboxes_status(geom, B, ws)
+    if status:
+        raise _lib.IouAwareLibraryError('fused row-max / filter launch reported status %d' % status)
     off = (C.c_size_t * 8)()
     _lib.check(L.ia_get_bboxes_workspace_layout(geom.ref(), B, C.byref(off)), 'workspace_layout')
 
@@ -242,6 +271,45 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
                keep_count=view(4, torch.int32, (B, geom.C)),
                keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)))
     return dets, labels, rows, num, dbg
+
+
+class DecodeStage(object):
+    """SURVEY 8(d)'s decode stage (row-max -> top-k -> gather / decode) as ONE C-ABI call into a
+    workspace allocated once: what ia_get_bboxes runs before its NMS.  `run()` launches it on the
+    current stream; `views()` are the stage's outputs inside the workspace."""
+
+    def __init__(self, geom, cls, reg, iou, img_shapes, scale_factors, rescale):
+        cls, reg, iou = list(cls), list(reg), list(iou)
+        self.p, self.B, self.dt, self.geom = level_ptrs(geom, cls, reg, iou)
+        self.keep = (cls, reg, iou)
+        dev = cls[0].device
+        L = _lib.lib()
+        self.nbytes = L.ia_get_bboxes_workspace_bytes(self.geom.ref(), self.B)
+        if self.nbytes == 0:
+            raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_decode_stage')
+        self.ws = torch.zeros(int(self.nbytes), dtype=torch.uint8, device=dev)     # WORKSPACE CONTRACT
+        self.hw, self.sf = _meta_tensors(img_shapes, scale_factors, dev)
+        self.rescale = int(bool(rescale))
+
+    def run(self):
+        _lib.check(_lib.lib().ia_decode_stage(self.geom.ref(), C.byref(self.p), self.B, self.dt,
+                                              _ptr(self.hw), _ptr(self.sf), self.rescale,
+                                              _ptr(self.ws), self.nbytes, _stream()),
+                   'ia_decode_stage')
+
+    def views(self):
+        off = (C.c_size_t * 8)()
+        _lib.check(_lib.lib().ia_get_bboxes_workspace_layout(self.geom.ref(), self.B, C.byref(off)),
+                   'workspace_layout')
+        g, B = self.geom, self.B
+
+        def view(i, dtype, shape):
+            n = int(np.prod(shape))
+            return self.ws[off[i]:off[i] + n * 4].view(dtype).view(*shape)
+        return dict(rowmax=view(0, torch.float32, (B, g.N)), cand_idx=view(1, torch.int32, (B, g.R)),
+                    boxes=view(2, torch.float32, (B, g.R, 4)),
+                    scores_t=view(3, torch.float32, (B, g.C, g.Rs)),
+                    best_score=view(6, torch.float32, (B, g.R)))
 
 
 # ----------------------------------------------------------------- stage wrappers

@@ -232,6 +232,14 @@ def _stage_chain(ops, geom, dc, dr, di, shapes, sfs):
     torch.cuda.synchronize()
     for a, b in zip(d1[:4], d2):
         assert torch.equal(a, b)
+    # ia_decode_stage: the first three stages in one call, in the ia_get_bboxes workspace
+    st = ops.DecodeStage(geom, dc, dr, di, shapes, sfs, True)
+    st.run()
+    v = st.views()
+    torch.cuda.synchronize()
+    assert torch.equal(v['rowmax'], rm) and torch.equal(v['cand_idx'], idx)
+    assert torch.equal(v['boxes'], boxes) and torch.equal(v['best_score'], best)
+    assert torch.equal(v['scores_t'][:, :, :geom.R], scores_t[:, :, :geom.R])
 
 
 def _numpy_topk(rowmax_ref_order, k):
@@ -315,6 +323,53 @@ def test_select_topk_filtered_paths(ops, ph, pw, B, nms_pre, kind, dtype):
                                                    int((got != want).sum()))
             off += n_l
             coff += k
+
+
+@pytest.mark.parametrize('kind', ['A', 'D'])
+def test_fused_rowmax_filter_launch_repeated_under_load(ops, kind):
+    """ia_decode_stage on channels-last heads: row-max wavefronts and the top-k filter workgroups
+    share ONE launch, the filter waiting for its segment's arrivals (write-through stores + agent
+    acquire).  60 back-to-back launches at BASELINE's size while a second stream keeps the memory
+    system busy: every launch must reproduce the separate kernels' row maxima and candidate list
+    word for word, and leave the status word at 0."""
+    ph, pw, B = 800, 1344, 8
+    g = torch.Generator(device='cuda').manual_seed(5)
+    cls, reg, iou = [], [], []
+    for (h, w) in synth.level_shapes(ph, pw):
+        if kind == 'D':
+            cls.append(-4.595 + torch.randn(B, 720, h, w, device='cuda', generator=g) * 0.0016)
+            iou.append(torch.randn(B, 9, h, w, device='cuda', generator=g) * 0.0019)
+        else:
+            cls.append(torch.randn(B, 720, h, w, device='cuda', generator=g) * 2 - 6)
+            iou.append(torch.randn(B, 9, h, w, device='cuda', generator=g) * 1.5)
+        reg.append(torch.randn(B, 36, h, w, device='cuda', generator=g) * 0.5)
+    cls, reg, iou = [[t.contiguous(memory_format=torch.channels_last) for t in x] for x in (cls, reg, iou)]
+    geom0, _ = G.geometry(ph, pw, 1000)
+    geom = ops.geometry_for(geom0, cls, reg, iou)
+    shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
+    rm = ops.decode_fuse_rowmax(geom, cls, reg, iou)          # the separate kernels
+    idx = ops.select_topk(geom, rm)
+    boxes, scores_t, best = ops.gather_decode(geom, cls, reg, iou, idx, shapes, sfs, True)
+    st = ops.DecodeStage(geom, cls, reg, iou, shapes, sfs, True)
+    v = st.views()
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    for it in range(60):
+        if it % 3 != 2:                                        # uneven load: two launches in three
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+        st.run()
+        bad += (v['cand_idx'] != idx).sum() + (v['rowmax'] != rm).sum() + (v['boxes'] != boxes).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
+    assert ops.get_bboxes_status(geom, B, st.ws) == 0
+    assert torch.equal(v['scores_t'][:, :, :geom.R], scores_t[:, :, :geom.R])
+    # the product entry point on its own state workspace, twice (the second call starts from the
+    # state the first one left behind)
+    for _ in range(2):
+        d = ops.get_bboxes(geom, cls, reg, iou, shapes, sfs, True, 0.05, 0.5, 100, debug=True)
+        assert torch.equal(d[4]['cand_idx'], idx) and torch.equal(d[4]['boxes'], boxes)
 
 
 # ------------------------------------------------------------------ nms op
