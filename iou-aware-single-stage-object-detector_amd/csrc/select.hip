@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
                 }
             }
         } else {
-            constexpr int DU = 4;                  // unpredicated loads, DU in flight per thread
+            constexpr int DU = 10;                 // unpredicated loads, DU in flight per thread (P5: one round)
             for (uint32_t base = 0; base < m; base += nt * DU) {
                 uint64_t xs[DU];
 #pragma unroll

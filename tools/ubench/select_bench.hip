@@ -10,6 +10,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include "../../iou-aware-single-stage-object-detector_amd/csrc/decode.hip"
 #include "../../iou-aware-single-stage-object-detector_amd/csrc/select.hip"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
