@@ -422,29 +422,76 @@ def test_config3_bf16_batch16_post_conv_path(oracle_lib):
     assert np.array_equal(one[2][0], rows[b])
 
 
+def _stage_outputs(m, x):
+    """backbone stages (C2..C5), FPN outputs (P3..P7), head outputs (cls / reg / iou per level)"""
+    feats = m.backbone(x)
+    pyr = m.neck(feats)
+    head = m.bbox_head(pyr)
+    return ([('C%d' % (i + 2), t) for i, t in enumerate(feats)] +
+            [('P%d' % (i + 3), t) for i, t in enumerate(pyr)] +
+            [('%s%d' % (n, i + 3), t) for n, ts in zip(('cls', 'reg', 'iou'), head)
+             for i, t in enumerate(ts)])
+
+
 def test_config3_r101_bf16_whole_network():
-    """R-101, bf16, channels-last, fused: the whole path runs and stays close to the fp32 module
-    path of the same weights (bf16 tolerance stated: 3e-2 of the logit scale -- 8 mantissa bits
-    through ~110 layers), detections mostly agree."""
+    """BASELINE config 3 (R-101, bf16, channels-last, fused epilogues / hipBLASLt GEMMs) stage by
+    stage.  Reference: the plain fp32 modules on the SAME bf16-rounded weights and input.  Two
+    comparators at every stage output (C2..C5, P3..P7, the 15 head outputs), error = RMS of the
+    difference / RMS of the reference:
+      * torch's own bf16 path (plain modules in bf16: MIOpen + eager BatchNorm / ReLU) -- the
+        fused path must not be worse than 1.5 x that + 1e-3: it rounds to bf16 once per
+        convolution where eager rounds after every elementwise op;
+      * an absolute bound per stage: 2^-8 (one bf16 ulp, relative) x 3 x sqrt(number of
+        convolutions in front of it) -- random-walk accumulation of one rounding per layer.
+    Detections: every fp32 detection with score > 0.3 has a bf16 twin (same class, IoU > 0.85)."""
+    import copy
     from iouaware.fuse import fuse_inference
     m = _trained_like(_build(dict(depth=101))).cuda()
-    x = torch.from_numpy(synth.e2e_image(9, 4, 256, 320, 256, 320)).cuda()
-    metas = [synth.img_meta(256, 320, 256, 320, 1.0)] * 4
     with torch.no_grad():
-        ref = m.forward_head(x)
+        for p_ in m.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
+        for b_ in m.buffers():
+            if b_.dtype == torch.float32:
+                b_.copy_(b_.to(torch.bfloat16).float())
+    x = torch.from_numpy(synth.e2e_image(9, 4, 256, 320, 256, 320)).cuda().to(torch.bfloat16).float()
+    metas = [synth.img_meta(256, 320, 256, 320, 1.0)] * 4
+    depth = dict(C2=10, C3=22, C4=91, C5=100)                 # convolutions in front (R-101: 3+4+23+3 blocks)
+    with torch.no_grad():
+        ref = _stage_outputs(m, x)
         ref_dets = m.simple_test_batch(x, metas, rescale=True)
+        eager = copy.deepcopy(m).to(torch.bfloat16)
+        eag = _stage_outputs(eager, x.to(torch.bfloat16))
+        del eager
         fuse_inference(m, winograd=True)
         mb = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        out = mb.forward_head(xb)
+        out = _stage_outputs(mb, xb)
         dets = mb.simple_test_batch(xb, metas, rescale=True)
-    for a, b in zip(ref, out):
-        for u, v in zip(a, b):
-            assert v.dtype == torch.bfloat16
-            e = float((u - v.float()).abs().max() / u.abs().max())
-            assert e < 3e-2, e
-    # high-confidence detections survive the precision change
+
+    def rms_rel(a, r):
+        return float((a.float() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt().clamp(min=1e-12))
+    lines = []
+    for (name, r), (_, e), (_, o) in zip(ref, eag, out):
+        assert o.dtype == torch.bfloat16
+        e_eager, e_fused = rms_rel(e, r), rms_rel(o, r)
+        nconv = depth.get(name, 100 + 2 + (10 if name[:3] in ('cls', 'reg', 'iou') else 0))
+        bound = 2.0 ** -8 * 3.0 * nconv ** 0.5
+        lines.append('%-5s fused %.2e  torch-bf16 %.2e  bound %.2e' % (name, e_fused, e_eager, bound))
+        assert e_fused <= 1.5 * e_eager + 1e-3, lines[-1]
+        assert e_fused <= bound, lines[-1]
+    _REPORT.append('config 3 (R-101 bf16) stage errors vs fp32 on bf16-rounded weights (RMS-relative):')
+    _REPORT.extend('      ' + ln for ln in lines)
+
+    def iou(a, b):
+        x1, y1 = np.maximum(a[0], b[:, 0]), np.maximum(a[1], b[:, 1])
+        x2, y2 = np.minimum(a[2], b[:, 2]), np.minimum(a[3], b[:, 3])
+        inter = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+        return inter / ((a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - inter)
+    strong = found = 0
     for d, d0 in zip(dets, ref_dets):
-        n0 = sum(len(a) for a in d0)
-        n = sum(len(a) for a in d)
-        assert n0 > 0 and abs(n - n0) <= max(5, n0 // 5)
+        for c in range(80):
+            for box in d0[c]:
+                if box[4] > 0.3:
+                    strong += 1
+                    found += int(len(d[c]) > 0 and float(iou(box, d[c]).max()) > 0.85)
+    assert strong > 0 and found == strong, (found, strong)

@@ -32,6 +32,9 @@ for k, d in out.items():
                                         + d.get("WRITE_SIZE_KB_per_launch", 0) * 1024)
 res = {"batch": $B, "inputs": "$KIND", "workload": "tools/time_head.py (head kernels, 800x1344)",
        "correction": "traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE counts 1/2)",
+       "stage_kernels": [k for k in out if k.startswith(("ia::k_rowmax_filter", "ia::k_sel_final", "ia::k_gather_nhwc"))],
+       "note": "stage_kernels = the launches of ia_decode_stage / ia_get_bboxes' decode stage (SURVEY 8d); "
+               "tools/time_head.py also runs the separate kernels of the stage-wise C-ABI",
        "kernels": out}
 json.dump(res, open("$ROOT/gpurun_out/pmc/head_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
