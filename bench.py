@@ -238,6 +238,9 @@ def cpu_baseline(model, stepper):
     name = cpu_model_name()
     return dict(value=round(1.0 / total, 4), unit='img/s', cores=threads, kind='port',
                 cpu=name, host_cores=os.cpu_count(),
+                configuration='latency-configured: ONE image at a time (the reference asserts batch 1 at '
+                              'test time, base.py:96-98); oneDNN convolutions at batch 1 scale poorly over '
+                              'the cores, the NMS is serial by construction -- not a throughput-tuned CPU run',
                 sample='1 image of the batch (3x800x1344): PyTorch-CPU convs %.2f s on %d threads'
                        ' + C oracle get_bboxes %.2f s on 1 thread (%d boxes into NMS); host: %s,'
                        ' %d cores' % (t_conv, threads, t_post, into_nms, name, os.cpu_count()),

@@ -30,6 +30,7 @@
 //                  stage holds) take the exact MSB-first radix select of ia_block.hpp.
 //
 // Levels with N_l <= nms_pre keep their natural order (the reference skips topk there, :537).
+#include <stdlib.h>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 #include "ia_rowmax_dev.hpp"
@@ -769,7 +770,13 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
     if (rc) return rc;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
     const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
-    bool fused = t.layout == IA_LAYOUT_NHWC && a.total_chunks > 0 && t.C % ppl == 0 && t.C / ppl <= kMaxVpr;
+    // IA_FUSED_ROWMAX_FILTER=0 in the environment: the separate kernels (A/B runs, bisecting)
+    static const bool allow_fused = [] {
+        const char *e = getenv("IA_FUSED_ROWMAX_FILTER");
+        return !(e && e[0] == '0');
+    }();
+    bool fused = allow_fused && t.layout == IA_LAYOUT_NHWC && a.total_chunks > 0 && t.C % ppl == 0 &&
+                 t.C / ppl <= kMaxVpr;
     for (int l = 0; l < t.num_levels && fused; ++l) fused = (((uintptr_t)p.cls[l] & 15u) == 0);
     RowmaxNhwcArgs ra;
     FusedOrder fo;
