@@ -201,9 +201,10 @@ int ia_decode_stage(const ia_head_geom *g, const ia_level_ptrs *p, int batch, in
 int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offsets[8]);
 
 /* mmdet.ops.nms.nms (mmdet/ops/nms/nms_wrapper.py:8-49 -> nms_cpu.nms /
- * nms_cuda.nms): dets (n,5) fp32 on device, n <= IA_MAX_CANDIDATES.
- * keep (n) int32 ascending input indices, count (1) int32; workspace holds the
- * n x n suppression bit matrix.                                               */
+ * nms_cuda.nms): dets (n,5) fp32 on device, ANY n like the reference op (up to
+ * IA_MAX_CANDIDATES boxes: one n x n suppression bit matrix; more: the same greedy NMS in
+ * chunks of IA_MAX_CANDIDATES sorted boxes, csrc/bignms.hip).
+ * keep (n) int32 ascending input indices, count (1) int32.                      */
 size_t ia_nms_workspace_bytes(int n);
 int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
            size_t workspace_bytes, void *stream);

@@ -388,11 +388,17 @@ int ia_get_bboxes_lazy(const ia_head_geom *g, const ia_level_ptrs *p, int batch,
                            num, stream);
 }
 
-size_t ia_nms_workspace_bytes(int n) { return ia::nms_single_workspace_bytes(n); }
+size_t ia_nms_workspace_bytes(int n)
+{
+    return n > IA_MAX_CANDIDATES ? ia::nms_big_workspace_bytes(n) : ia::nms_single_workspace_bytes(n);
+}
 
 int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
            size_t workspace_bytes, void *stream)
 {
+    if (n > IA_MAX_CANDIDATES)              // no size limit, like nms_cpu.cpp: chunked (bignms.hip)
+        return ia::launch_nms_big(dets, n, iou_thr, keep, count, workspace, workspace_bytes,
+                                  (hipStream_t)stream);
     return ia::launch_nms_single(dets, n, iou_thr, keep, count, workspace, workspace_bytes,
                                  (hipStream_t)stream);
 }

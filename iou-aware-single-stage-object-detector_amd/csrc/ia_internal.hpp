@@ -140,6 +140,10 @@ int launch_lazy_nms(const float *boxes, const float *scores_t, int batch, int R,
                     void *workspace, float *dets, int32_t *labels, int32_t *rows, int32_t *num,
                     int32_t *need_full, hipStream_t s);
 size_t nms_single_workspace_bytes(int n);
+// more than IA_MAX_CANDIDATES boxes: chunked NMS (bignms.hip), same result
+size_t nms_big_workspace_bytes(int n);
+int launch_nms_big(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
+                   void *workspace, size_t workspace_bytes, hipStream_t s);
 int launch_nms_single(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
                       void *workspace, size_t workspace_bytes, hipStream_t s);
 

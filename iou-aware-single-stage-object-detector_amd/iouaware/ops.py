@@ -472,9 +472,6 @@ def nms_indices(dets, iou_thr):
     n = dets.shape[0]
     if n == 0:
         return dets.new_zeros(0, dtype=torch.long)
-    if n > _lib.IA_MAX_CANDIDATES:
-        raise _lib.IouAwareLibraryError('nms supports at most %d boxes per call, got %d'
-                                        % (_lib.IA_MAX_CANDIDATES, n))
     d = dets.detach().to(torch.float32).contiguous()
     keep = torch.empty((n,), dtype=torch.int32, device=dets.device)
     cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)

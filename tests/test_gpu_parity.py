@@ -420,8 +420,27 @@ def test_nms_op_sizes(ops, oracle_lib, n):
 def test_nms_op_empty_and_limits(ops):
     from iouaware import _lib
     assert ops.nms_indices(torch.zeros(0, 5).cuda(), 0.5).numel() == 0
-    with pytest.raises(_lib.IouAwareLibraryError):
-        ops.nms_indices(torch.zeros(8193, 5).cuda(), 0.5)
+    with pytest.raises(_lib.IouAwareLibraryError):          # soft-NMS keeps its single-problem limit
+        ops.soft_nms_dets(torch.zeros(8193, 5).cuda(), 0.5)
+
+
+@pytest.mark.parametrize('n,extent,ties', [(8193, 600, True), (8192 * 2, 3000, False), (20001, 900, True),
+                                           (40000, 6000, False), (30000, 250, True)])
+def test_nms_op_beyond_one_chunk(ops, oracle_lib, n, extent, ties):
+    """mmdet.ops.nms.nms has no size limit (nms_cpu.cpp:4-59); above IA_MAX_CANDIDATES ia_nms
+    runs the same greedy NMS over chunks of sorted boxes (bignms.hip).  Dense scenes (nearly
+    everything suppressed by earlier chunks), sparse scenes (kept list of several thousand
+    boxes) and score ties across chunk borders, bit-exact against the oracle."""
+    rs = np.random.RandomState(n)
+    x1, y1 = rs.uniform(0, extent, n), rs.uniform(0, extent, n)
+    sc = rs.randint(0, n // 5, n) / float(n) if ties else rs.uniform(0, 1, n)
+    dets = np.stack([x1, y1, x1 + rs.uniform(4, 150, n), y1 + rs.uniform(4, 150, n), sc],
+                    1).astype(np.float32)
+    want = oracle_lib.nms(dets, 0.5)
+    d = torch.from_numpy(dets).cuda()
+    got = ops.nms_indices(d, 0.5).cpu().numpy()
+    assert np.array_equal(got, want), (len(got), len(want))
+    assert np.array_equal(ops.nms_indices(d, 0.5).cpu().numpy(), want)      # workspace reuse
 
 
 # ------------------------------------------------------------------ full size, batch 8
