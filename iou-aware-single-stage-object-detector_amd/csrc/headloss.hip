@@ -482,11 +482,17 @@ __global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
     const float gs = BWD ? upstream(a.gin, a.res, a.lv.L, 0, l, a.loss_weight) : 1.0f;
     const float *cls = a.cls[l];
     const int64_t ps = a.ps_cls[l], pg = BWD ? a.ps_grad[l] : 0;
+    // every load of the thread is issued before the first use (addresses clamped, no predicate):
+    // a load next to its use, or under `on ? load : 0`, compiles to load + s_waitcnt vmcnt(0)
+    // per piece, i.e. eight dependent memory round trips per thread instead of one
     float4 v[kFocalU];
-    int64_t anchor[kFocalU];
+    int32_t labv[kFocalU];
+    float lwv[kFocalU];
     int cq[kFocalU];
     int64_t goff[kFocalU];
     bool on[kFocalU];
+    const int32_t *labels = reinterpret_cast<const int32_t *>(a.labels[l]);   // low words: labels < 2^31
+    const float *lwp = a.lw[l];
 #pragma unroll
     for (int u = 0; u < kFocalU; ++u) {
         int j = (int)threadIdx.x + 256 * u;
@@ -497,18 +503,20 @@ __global__ void __launch_bounds__(256) k_focal_nhwc(FocalNhwcArgs a)
         const int64_t pix = pix0 + dp;                      // (b, p)
         const int r = rr - dp * AC4;                        // a * C4 + class quad
         const int an = (int)(((float)r + 0.5f) * inv_c4);
-        anchor[u] = pix * A + an;
+        const int64_t anchor = pix * A + an;
         cq[u] = r - an * C4;
         typedef float F4 __attribute__((ext_vector_type(4)));
         const F4 q = __builtin_nontemporal_load(reinterpret_cast<const F4 *>(cls + pix * ps + 4 * r));
         v[u] = make_float4(q.x, q.y, q.z, q.w);
+        labv[u] = labels[2 * anchor];
+        lwv[u] = lwp[anchor];
         goff[u] = pix * pg + 4 * r;
     }
     double total = 0.0;
 #pragma unroll
     for (int u = 0; u < kFocalU; ++u) {
-        const int lab = (int)a.labels[l][anchor[u]];
-        const float w0 = on[u] ? a.lw[l][anchor[u]] : 0.0f;
+        const int lab = labv[u];
+        const float w0 = on[u] ? lwv[u] : 0.0f;
         const float wn = (a.alpha_neg * w0) * gs, wp = (a.alpha_pos * w0) * gs;
         const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
         float t[4], rq[4], lg[4];

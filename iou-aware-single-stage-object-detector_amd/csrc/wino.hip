@@ -22,6 +22,7 @@
 // (interpolation points 0, +-1, +-2, inf); weights are transformed once on the host side
 // (U = G g G^T in fp64, iouaware/winograd.py).
 #include <string.h>
+#include <type_traits>
 #include "ia_internal.hpp"
 
 namespace ia {
@@ -95,13 +96,32 @@ __device__ __forceinline__ TileRef locate_tile(const WinoLevels &w, int t, int *
     return r;
 }
 
+// `opaque`: the value stays in scalar registers and the compiler cannot see through it.  Without
+// it a chain of selects over table entries is folded back into ONE load at a selected address --
+// a vector load from the kernarg segment whose round trip sits in front of the first pixel load.
 template <typename P>
+__device__ __forceinline__ P opaque(P v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// UNIFORM: l is the same for the whole wavefront (one tile per wavefront) -> a scalar load
+template <bool UNIFORM, typename P>
 __device__ __forceinline__ P level_ptr(P const (&tab)[IA_MAX_LEVELS], int l)
 {
-    P p = tab[0];
+    if (UNIFORM) return tab[l];
+    // selected as a byte offset from tab[0]: the asm would hide that a pointer passed through
+    // it is a kernel-argument (global) pointer and every access would become flat_load / _store
+    typedef typename std::remove_pointer<P>::type E;
+    const char *base = reinterpret_cast<const char *>(tab[0]);
+    int64_t d = 0;
 #pragma unroll
-    for (int i = 1; i < IA_MAX_LEVELS; ++i) p = (l == i) ? tab[i] : p;
-    return p;
+    for (int i = 1; i < IA_MAX_LEVELS; ++i) {
+        const int64_t di = opaque((int64_t)(reinterpret_cast<const char *>(tab[i]) - base));
+        d = (l == i) ? di : d;
+    }
+    return reinterpret_cast<P>(const_cast<char *>(base + d));
+    (void)sizeof(E);
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -158,18 +178,21 @@ struct WinoInArgs {
 // the 64- and 128-channel bottleneck layers ran at 2.5-3.8 TB/s with 16 / 32 live lanes, the
 // 48-column reg|iou output transform at 0.7 TB/s with 12.
 struct LaneMap { int t, c; bool on; };
+// PACKED = false: one tile per wavefront -- the tile, its level and every table entry are
+// wavefront-uniform (scalar registers, scalar loads)
+template <bool PACKED>
 __device__ __forceinline__ LaneMap lane_map(int Ctot, int T, int tpw)
 {
     LaneMap m;
     const int lane = threadIdx.x;
-    if (tpw > 1) {
+    if (PACKED) {
         const int q = Ctot >> 2;                       // quads per tile, <= 32 here
         const int sub = lane / q;
         const int tw = xcd_tile(blockIdx.x, (T + tpw - 1) / tpw) * tpw + sub;
         m.t = tw; m.c = (lane - sub * q) * 4;
         m.on = (sub < tpw) && (tw < T);
     } else {
-        m.t = xcd_tile(blockIdx.x, T);
+        m.t = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, T));
         m.c = (blockIdx.y * 64 + lane) * 4;
         m.on = (m.c < Ctot) && (m.t < T);
     }
@@ -181,14 +204,15 @@ static int tiles_per_wave(int channels)
     return (q < 64) ? (64 / q) : 1;
 }
 
+template <bool PACKED>
 __global__ void __launch_bounds__(64) k_wino_in(WinoInArgs a)
 {
-    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    const LaneMap lm = lane_map<PACKED>(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
     int H, W;
     const TileRef r = locate_tile(a.lv, t, &H, &W);
-    const float *x = level_ptr(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
+    const float *x = level_ptr<!PACKED>(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
     const bool pre = a.pre_shift != nullptr;
     float4 ps = f4(1.0f), pb = f4(0.0f);
     if (pre) {
@@ -274,14 +298,15 @@ __device__ __forceinline__ void a6(const float4 (&y)[4], float4 (&o)[6])
 // Gradient of the output transform (training, weight gradient in the Winograd domain):
 // dM = A dY A^T per tile, dY = the 4x4 output pixels of the tile (zero outside the feature map,
 // where the forward output transform wrote nothing), scattered as 36 matrices like V.
+template <bool PACKED>
 __global__ void __launch_bounds__(64) k_wino_dy(WinoInArgs a)
 {
-    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    const LaneMap lm = lane_map<PACKED>(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
     int H, W;
     const TileRef r = locate_tile(a.lv, t, &H, &W);
-    const float *x = level_ptr(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
+    const float *x = level_ptr<!PACKED>(a.x, r.l) + (size_t)r.b * H * W * a.Ctot + c;
     float4 d[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -333,9 +358,10 @@ struct WinoOutArgs {
     int32_t nseg, Ctot, Cg, T, relu, tpw;
 };
 
+template <bool PACKED>
 __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
 {
-    const LaneMap lm = lane_map(a.Ctot, a.T, a.tpw);
+    const LaneMap lm = lane_map<PACKED>(a.Ctot, a.T, a.tpw);
     if (!lm.on) return;
     const int t = lm.t, c = lm.c;
     int H, W;
@@ -343,6 +369,11 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
     const int g = c / a.Cg, cc = c - g * a.Cg;
     const float *m = a.M + ((size_t)g * 36 * a.T + t) * a.Cg + cc;
     const size_t kstride = (size_t)a.T * a.Cg;
+    // the bias is the OLDEST load: were it issued after the 36 loads of M, its s_waitcnt vmcnt(0)
+    // would sit in the store phase, where (behind the per-pixel branches) it is repeated in front
+    // of every pixel and waits for all the stores issued so far
+    float4 bz = f4(0.0f);
+    if (a.bias) bz = *reinterpret_cast<const float4 *>(a.bias + c);
     float4 s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {                       // columns: s = A^T m
@@ -353,14 +384,23 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i][j] = o[i];
     }
-    float4 bz = f4(0.0f);
-    if (a.bias) bz = *reinterpret_cast<const float4 *>(a.bias + c);
-    // destination of this lane's four channels
-    int si = 0;
-    while (si + 1 < a.nseg && c >= a.seg[si].c0 + a.seg[si].n) ++si;
-    const WinoSeg &sg = a.seg[si];
-    const bool whole = (c >= sg.c0) && (c + 4 <= sg.c0 + sg.n) && (((sg.coff + c - sg.c0) & 3) == 0) &&
-                       ((sg.Cdst & 3) == 0);
+    // Destination of this lane's four channels: the last segment that starts at or before c
+    // (segments ascend).  Its parameters are selected ONCE into registers from scalar loads;
+    // `a.seg[si]` with a per-lane si was a vector load from the kernarg segment that the compiler
+    // re-issued in front of every one of the 16 stores (load, s_waitcnt vmcnt(0), store).
+    int sc0 = opaque(a.seg[0].c0), sn = opaque(a.seg[0].n), sC = opaque(a.seg[0].Cdst), soff = opaque(a.seg[0].coff);
+    float *sdst = level_ptr<!PACKED>(a.seg[0].dst, r.l);
+#pragma unroll
+    for (int k = 1; k < kMaxSeg; ++k) {
+        const int kc0 = opaque(a.seg[k].c0), kn = opaque(a.seg[k].n), kC = opaque(a.seg[k].Cdst),
+                  koff = opaque(a.seg[k].coff);
+        float *kdst = level_ptr<!PACKED>(a.seg[k].dst, r.l);
+        const bool m = (k < a.nseg) && (c >= kc0);
+        sc0 = m ? kc0 : sc0; sn = m ? kn : sn; sC = m ? kC : sC; soff = m ? koff : soff;
+        sdst = m ? kdst : sdst;
+    }
+    const bool whole = (c >= sc0) && (c + 4 <= sc0 + sn) && (((soff + c - sc0) & 3) == 0) && ((sC & 3) == 0);
+    float *const dst0 = sdst + soff + (c - sc0);
     // a lane that straddles segments / padding, or whose destination is not 16-byte aligned
     // (the 9-channel IoU output): destination of each of its four channels, resolved once
     float *qdst[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -372,7 +412,7 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
             for (int k = 0; k < a.nseg; ++k) {
                 const WinoSeg &z = a.seg[k];
                 if (ch >= z.c0 && ch < z.c0 + z.n) {
-                    qdst[q] = z.dst[r.l]; qC[q] = z.Cdst; qoff[q] = z.coff + (ch - z.c0);
+                    qdst[q] = level_ptr<!PACKED>(z.dst, r.l); qC[q] = z.Cdst; qoff[q] = z.coff + (ch - z.c0);
                 }
             }
         }
@@ -391,7 +431,7 @@ __global__ void __launch_bounds__(64) k_wino_out(WinoOutArgs a)
                                         v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
             const size_t pix = ((size_t)r.b * H + y) * W + xx;
             if (whole) {
-                *reinterpret_cast<float4 *>(sg.dst[r.l] + pix * sg.Cdst + sg.coff + (c - sg.c0)) = v;
+                *reinterpret_cast<float4 *>(dst0 + pix * sC) = v;
             } else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -435,7 +475,8 @@ int ia_wino_input_transform(const ia_wino_geom *g, const float *const *x, int ch
     a.tpw = ia::tiles_per_wave(channels);
     const int waves = (a.T + a.tpw - 1) / a.tpw;
     dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
-    hipLaunchKernelGGL(ia::k_wino_in, grid, dim3(64), 0, (hipStream_t)stream, a);
+    if (a.tpw > 1) hipLaunchKernelGGL(ia::k_wino_in<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ia::k_wino_in<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 
@@ -456,7 +497,8 @@ int ia_wino_grad_output_transform(const ia_wino_geom *g, const float *const *dy,
     a.tpw = ia::tiles_per_wave(channels);
     const int waves = (a.T + a.tpw - 1) / a.tpw;
     dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
-    hipLaunchKernelGGL(ia::k_wino_dy, grid, dim3(64), 0, (hipStream_t)stream, a);
+    if (a.tpw > 1) hipLaunchKernelGGL(ia::k_wino_dy<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ia::k_wino_dy<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 
@@ -489,7 +531,8 @@ int ia_wino_output_transform(const ia_wino_geom *g, const float *M, int channels
     a.tpw = ia::tiles_per_wave(channels);
     const int waves = (a.T + a.tpw - 1) / a.tpw;
     dim3 grid((unsigned)((waves + 7) / 8 * 8), (unsigned)((channels / 4 + 63) / 64));
-    hipLaunchKernelGGL(ia::k_wino_out, grid, dim3(64), 0, (hipStream_t)stream, a);
+    if (a.tpw > 1) hipLaunchKernelGGL(ia::k_wino_out<true>, grid, dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ia::k_wino_out<false>, grid, dim3(64), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 
