@@ -11,6 +11,7 @@ call (BASELINE configs 2, 3) and the whole post-conv path is one library call.
 """
 import logging
 
+import torch
 import torch.nn as nn
 
 from . import registry
@@ -110,12 +111,44 @@ class SingleStageDetector(BaseDetector):
                                                         self.test_cfg, rescale)))
         return [bbox2result(d, l, self.bbox_head.num_classes) for d, l in bbox_list]
 
+    def simple_test_batch_submit(self, img, img_meta, rescale=False):
+        """Asynchronous half of simple_test_batch for a serving loop: enqueues the network, the
+        decode / NMS stage and the one device-to-host copy (into a pinned buffer) and returns
+        at once; `PendingResults.collect()` waits for that copy and builds the per-class arrays.
+        Submitting batch i+1 before collecting batch i overlaps the host's bbox2result with the
+        device's work (the records of batch i are complete before batch i+1 touches any shared
+        workspace: same stream)."""
+        from .dist import pack_detections
+        if not (hasattr(self.bbox_head, 'get_bboxes_batched') and img.is_cuda):
+            raise RuntimeError('simple_test_batch_submit needs the batched HIP head on a ROCm device')
+        dets, labels, _, num = self.simple_test_device(img, img_meta, rescale)
+        rec = pack_detections(dets, labels, num)
+        host = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+        host.copy_(rec, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return PendingResults(host, done, dets.shape[1], self.bbox_head.num_classes)
+
     def simple_test(self, img, img_meta, gt_bboxes=None, gt_labels=None, rescale=False):
         results = self.simple_test_batch(img, img_meta, gt_bboxes, gt_labels, rescale)
         return results[0] if len(results) == 1 else results
 
     def aug_test(self, imgs, img_metas, rescale=False):
         raise NotImplementedError
+
+
+class PendingResults(object):
+    """detections of one submitted batch, still on their way to the host"""
+
+    def __init__(self, host, done, max_per_img, num_classes):
+        self._host, self._done, self._m, self._nc = host, done, max_per_img, num_classes
+
+    def collect(self):
+        from .dist import unpack_detections
+        self._done.synchronize()
+        dets, labels, num = unpack_detections(self._host, self._m)
+        dets, labels, num = dets.numpy(), labels.numpy(), num.tolist()
+        return [bbox2result(dets[b, :k], labels[b, :k], self._nc) for b, k in enumerate(num)]
 
 
 @DETECTORS.register_module

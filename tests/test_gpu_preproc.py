@@ -85,3 +85,18 @@ def test_transform_feeds_the_detector():
     with torch.no_grad():
         res = m.simple_test_batch(imgs, metas, rescale=True)
     assert len(res) == 2 and all(len(r) == 80 for r in res)       # bbox2result lists per image
+    # serving loop: two batches in flight, collected out of step with their submission
+    # (the library convolutions of the module path are not bit-reproducible from call to call --
+    # head outputs move by an ulp, boxes by ~1e-5 -- hence a tolerance, not array_equal)
+    same = lambda x, y: all(a.shape == b.shape and (a.size == 0 or np.abs(a - b).max() < 1e-4)
+                            for ra, rb in zip(x, y) for a, b in zip(ra, rb))
+    flipped = imgs.flip(0).contiguous()
+    with torch.no_grad():
+        res = m.simple_test_batch(imgs, metas, rescale=True)          # conv algorithms settled
+        again = m.simple_test_batch(flipped, metas[::-1], rescale=True)
+        p1 = m.simple_test_batch_submit(imgs, metas, rescale=True)
+        p2 = m.simple_test_batch_submit(flipped, metas[::-1], rescale=True)
+        res_after = m.simple_test_batch(imgs, metas, rescale=True)
+    assert same(res_after, res)
+    assert same(p2.collect(), again)
+    assert same(p1.collect(), res)
