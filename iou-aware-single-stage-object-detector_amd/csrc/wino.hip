@@ -22,7 +22,6 @@
 // (interpolation points 0, +-1, +-2, inf); weights are transformed once on the host side
 // (U = G g G^T in fp64, iouaware/winograd.py).
 #include <string.h>
-#include <type_traits>
 #include "ia_internal.hpp"
 
 namespace ia {
@@ -112,7 +111,6 @@ __device__ __forceinline__ P level_ptr(P const (&tab)[IA_MAX_LEVELS], int l)
     if (UNIFORM) return tab[l];
     // selected as a byte offset from tab[0]: the asm would hide that a pointer passed through
     // it is a kernel-argument (global) pointer and every access would become flat_load / _store
-    typedef typename std::remove_pointer<P>::type E;
     const char *base = reinterpret_cast<const char *>(tab[0]);
     int64_t d = 0;
 #pragma unroll
@@ -121,7 +119,6 @@ __device__ __forceinline__ P level_ptr(P const (&tab)[IA_MAX_LEVELS], int l)
         d = (l == i) ? di : d;
     }
     return reinterpret_cast<P>(const_cast<char *>(base + d));
-    (void)sizeof(E);
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
