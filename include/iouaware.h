@@ -554,11 +554,18 @@ int ia_nhwc_to_nchw(const void *src, void *dst, int dtype, int N, int C, int64_t
  * out (B, (H-1)/2+1, (W-1)/2+1, C).                                                          */
 int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift, int B, int H,
                                 int W, int C, float *out, void *stream);
+/* the same for dtype IA_F32 / IA_BF16 (C % 4 / C % 8 == 0): fp32 arithmetic, a bf16 result is
+ * rounded once -- equal to eager's affine -> ReLU -> max-pool on bf16 values                      */
+int ia_affine_relu_maxpool_nhwc_dt(const void *x, int dtype, const float *scale, const float *shift,
+                                   int B, int H, int W, int C, void *out, void *stream);
 
 /* FPN top-down step, in place (mmdet/models/necks/fpn.py:118-120): fine += nearest-x2(coarse);
  * channels-last fp32, H = 2*Hc, W = 2*Wc, C % 4 == 0.                                          */
 int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W, int Hc, int Wc,
                            int C, void *stream);
+/* dtype IA_F32 / IA_BF16 (C % 4 / C % 8 == 0); bf16: one rounding of the fp32 sum, like eager's add */
+int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, int H, int W, int Hc,
+                              int Wc, int C, void *stream);
 
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the

@@ -349,64 +349,96 @@ extern "C" int ia_channel_affine_act(void *x, int dtype, const float *scale, con
 namespace ia {
 
 struct PoolArgs {
-    const float *x;              // (B, H, W, C)
+    const void *x;               // (B, H, W, C) fp32 / bf16
     const float *scale, *shift;  // (C)
-    float *out;                  // (B, Ho, Wo, C)
+    void *out;                   // (B, Ho, Wo, C)
     int32_t B, H, W, C, Ho, Wo;
 };
 
+// one thread: 16 bytes of channels (4 fp32 / 8 bf16) of one output pixel; the arithmetic is fp32,
+// a bf16 output is rounded once at the end (rounding and ReLU are monotonic: the result equals
+// affine -> round -> ReLU -> max-pool on bf16 values, the eager sequence)
+template <typename T>
 __global__ void __launch_bounds__(256) k_affine_relu_maxpool(PoolArgs a)
 {
-    const int c4n = a.C / 4;
+    constexpr int N = Pack<T>::N;
+    using V = typename Pack<T>::V;
+    const int cvn = a.C / N;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * c4n;
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * cvn;
     if (gid >= total) return;
-    const int c = (int)(gid % c4n) * 4;
-    int64_t p = gid / c4n;
+    const int c = (int)(gid % cvn) * N;
+    int64_t p = gid / cvn;
     const int xo = (int)(p % a.Wo); p /= a.Wo;
     const int yo = (int)(p % a.Ho);
     const int b = (int)(p / a.Ho);
-    const float4 s = *reinterpret_cast<const float4 *>(a.scale + c);
-    const float4 t = *reinterpret_cast<const float4 *>(a.shift + c);
-    const float ninf = -__builtin_inff();
-    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    float s[N], t[N], m[N];
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+        const float4 s4 = *reinterpret_cast<const float4 *>(a.scale + c + j);
+        const float4 t4 = *reinterpret_cast<const float4 *>(a.shift + c + j);
+        s[j] = s4.x; s[j + 1] = s4.y; s[j + 2] = s4.z; s[j + 3] = s4.w;
+        t[j] = t4.x; t[j + 1] = t4.y; t[j + 2] = t4.z; t[j + 3] = t4.w;
+    }
+    const T *x = static_cast<const T *>(a.x);
+    V taps[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int y = 2 * yo - 1 + dy;
         const int yc = (y < 0) ? 0 : ((y >= a.H) ? a.H - 1 : y);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int x = 2 * xo - 1 + dx;
-            const int xc = (x < 0) ? 0 : ((x >= a.W) ? a.W - 1 : x);
+            const int xx = 2 * xo - 1 + dx;
+            const int xc = (xx < 0) ? 0 : ((xx >= a.W) ? a.W - 1 : xx);
             // clamped address: the duplicate of an in-range tap never changes a maximum
-            const float4 v = *reinterpret_cast<const float4 *>(
-                a.x + (((size_t)b * a.H + yc) * a.W + xc) * a.C + c);
-            const float4 w = make_float4(v.x * s.x + t.x, v.y * s.y + t.y, v.z * s.z + t.z, v.w * s.w + t.w);
-            m.x = (m.x < w.x) ? w.x : m.x; m.y = (m.y < w.y) ? w.y : m.y;
-            m.z = (m.z < w.z) ? w.z : m.z; m.w = (m.w < w.w) ? w.w : m.w;
+            taps[dy * 3 + dx] = *reinterpret_cast<const V *>(x + (((size_t)b * a.H + yc) * a.W + xc) * a.C + c);
         }
     }
-    m.x = (m.x > 0.f) ? m.x : 0.f; m.y = (m.y > 0.f) ? m.y : 0.f;
-    m.z = (m.z > 0.f) ? m.z : 0.f; m.w = (m.w > 0.f) ? m.w : 0.f;
-    *reinterpret_cast<float4 *>(a.out + (((size_t)b * a.Ho + yo) * a.Wo + xo) * a.C + c) = m;
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[j] = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float v[N];
+        Pack<T>::unpack(taps[k], v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float w = v[j] * s[j] + t[j];
+            m[j] = (m[j] < w) ? w : m[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[j] = (m[j] > 0.f) ? m[j] : 0.f;
+    *reinterpret_cast<V *>(static_cast<T *>(a.out) + (((size_t)b * a.Ho + yo) * a.Wo + xo) * a.C + c) = Pack<T>::pack(m);
 }
 
 }  // namespace ia
 
-extern "C" int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift,
-                                           int B, int H, int W, int C, float *out, void *stream)
+extern "C" int ia_affine_relu_maxpool_nhwc_dt(const void *x, int dtype, const float *scale, const float *shift,
+                                              int B, int H, int W, int C, void *out, void *stream)
 {
-    if (!x || !scale || !shift || !out || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return IA_E_ARG;
+    if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    const int vec = (dtype == IA_F32) ? 4 : 8;
+    if (!x || !scale || !shift || !out || B < 1 || H < 1 || W < 1 || C < vec || (C % vec)) return IA_E_ARG;
+    if (((uintptr_t)x & 15u) || ((uintptr_t)out & 15u) || ((uintptr_t)scale & 15u) || ((uintptr_t)shift & 15u))
+        return IA_E_ARG;
     ia::PoolArgs a;
     a.x = x; a.scale = scale; a.shift = shift; a.out = out;
     a.B = B; a.H = H; a.W = W; a.C = C;
     a.Ho = (H + 2 - 3) / 2 + 1; a.Wo = (W + 2 - 3) / 2 + 1;
-    const int64_t total = (int64_t)B * a.Ho * a.Wo * (C / 4);
+    const int64_t total = (int64_t)B * a.Ho * a.Wo * (C / vec);
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 2147483647LL) return IA_E_ARG;
-    hipLaunchKernelGGL(ia::k_affine_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    if (dtype == IA_F32)
+        hipLaunchKernelGGL(ia::k_affine_relu_maxpool<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ia::k_affine_relu_maxpool<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
+}
+
+extern "C" int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, const float *shift,
+                                           int B, int H, int W, int C, float *out, void *stream)
+{
+    return ia_affine_relu_maxpool_nhwc_dt(x, IA_F32, scale, shift, B, H, W, C, out, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -418,19 +450,22 @@ extern "C" int ia_affine_relu_maxpool_nhwc(const float *x, const float *scale, c
 namespace ia {
 
 struct UpAddArgs {
-    float *fine;                 // (B, H, W, C)
-    const float *coarse;         // (B, Hc, Wc, C)
+    void *fine;                  // (B, H, W, C) fp32 / bf16
+    const void *coarse;          // (B, Hc, Wc, C)
     int32_t B, H, W, Hc, Wc, C;
 };
 
+template <typename T>
 __global__ void __launch_bounds__(256) k_upsample_add(UpAddArgs a)
 {
-    const int c4n = a.C / 4;
+    constexpr int N = Pack<T>::N;
+    using V = typename Pack<T>::V;
+    const int cvn = a.C / N;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)a.B * a.H * a.W * c4n;
+    const int64_t total = (int64_t)a.B * a.H * a.W * cvn;
     if (gid >= total) return;
-    const int c = (int)(gid % c4n) * 4;
-    int64_t p = gid / c4n;
+    const int c = (int)(gid % cvn) * N;
+    int64_t p = gid / cvn;
     const int x = (int)(p % a.W); p /= a.W;
     const int y = (int)(p % a.H);
     const int b = (int)(p / a.H);
@@ -439,27 +474,43 @@ __global__ void __launch_bounds__(256) k_upsample_add(UpAddArgs a)
     int ys = y >> 1, xs = x >> 1;
     ys = (ys < a.Hc) ? ys : a.Hc - 1;
     xs = (xs < a.Wc) ? xs : a.Wc - 1;
-    float4 *f = reinterpret_cast<float4 *>(a.fine + (((size_t)b * a.H + y) * a.W + x) * a.C + c);
-    const float4 u = *reinterpret_cast<const float4 *>(
-        a.coarse + (((size_t)b * a.Hc + ys) * a.Wc + xs) * a.C + c);
-    float4 v = *f;
-    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    *f = v;
+    V *f = reinterpret_cast<V *>(static_cast<T *>(a.fine) + (((size_t)b * a.H + y) * a.W + x) * a.C + c);
+    const V uq = *reinterpret_cast<const V *>(static_cast<const T *>(a.coarse) +
+                                             (((size_t)b * a.Hc + ys) * a.Wc + xs) * a.C + c);
+    const V vq = *f;
+    float u[N], v[N];
+    Pack<T>::unpack(uq, u);
+    Pack<T>::unpack(vq, v);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] += u[j];             // bf16: one rounding of the fp32 sum, like eager's add
+    *f = Pack<T>::pack(v);
 }
 
 }  // namespace ia
 
-extern "C" int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W, int Hc,
-                                      int Wc, int C, void *stream)
+extern "C" int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, int H, int W,
+                                         int Hc, int Wc, int C, void *stream)
 {
-    if (!fine || !coarse || B < 1 || H < 1 || W < 1 || Hc < 1 || Wc < 1 || C < 4 || (C & 3))
+    if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    const int vec = (dtype == IA_F32) ? 4 : 8;
+    if (!fine || !coarse || B < 1 || H < 1 || W < 1 || Hc < 1 || Wc < 1 || C < vec || (C % vec))
         return IA_E_ARG;
+    if (((uintptr_t)fine & 15u) || ((uintptr_t)coarse & 15u)) return IA_E_ARG;
     if (H != 2 * Hc || W != 2 * Wc) return IA_E_ARG;      // scale_factor = 2 exactly (fpn.py:119)
     ia::UpAddArgs a;
     a.fine = fine; a.coarse = coarse; a.B = B; a.H = H; a.W = W; a.Hc = Hc; a.Wc = Wc; a.C = C;
-    const int64_t total = (int64_t)B * H * W * (C / 4);
+    const int64_t total = (int64_t)B * H * W * (C / vec);
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 2147483647LL) return IA_E_ARG;
-    hipLaunchKernelGGL(ia::k_upsample_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (dtype == IA_F32)
+        hipLaunchKernelGGL(ia::k_upsample_add<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ia::k_upsample_add<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
+}
+
+extern "C" int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W, int Hc,
+                                      int Wc, int C, void *stream)
+{
+    return ia_upsample2x_add_nhwc_dt(fine, coarse, IA_F32, B, H, W, Hc, Wc, C, stream);
 }

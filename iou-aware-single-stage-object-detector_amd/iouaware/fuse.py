@@ -30,6 +30,9 @@ from . import ops, train_fuse
 from .backbones import BasicBlock, Bottleneck, ResNet
 from .layers import ConvModule
 
+# channels per 16-byte vector of the fused elementwise kernels
+_VEC = {torch.float32: 4, torch.bfloat16: 8}
+
 
 def _fold_bn(bn):
     if not isinstance(bn, _BatchNorm):
@@ -195,7 +198,7 @@ def _resnet_stem(self, x):
     f = self._ia_fused
     x = self.conv1(x)
     mp = self.maxpool
-    if f.get('pool') and x.dtype == torch.float32 and x.shape[1] % 4 == 0 \
+    if f.get('pool') and x.dtype in _VEC and x.shape[1] % _VEC[x.dtype] == 0 \
             and x.is_contiguous(memory_format=torch.channels_last):
         x = ops.affine_relu_maxpool(x, f['s'], f['b'])          # BN + ReLU + 3x3/2 max-pool, one pass
     else:
@@ -238,8 +241,9 @@ def _fpn_forward(self, inputs):
     # The lateral convolutions keep the layout / dtype of their inputs and have
     # out_channels outputs, which is all the fused top-down kernel needs to know.
     ok = (not self.training) and (not torch.is_grad_enabled()) \
-        and len(inputs) == len(self.in_channels) and self.out_channels % 4 == 0 and all(
-            t.is_cuda and t.dtype == torch.float32
+        and len(inputs) == len(self.in_channels) and all(
+            t.is_cuda and t.dtype in _VEC and t.dtype == inputs[0].dtype
+            and self.out_channels % _VEC[t.dtype] == 0
             and t.is_contiguous(memory_format=torch.channels_last)
             for t in inputs[self.start_level:self.backbone_end_level])
     if not ok:

@@ -512,26 +512,37 @@ def channel_affine_act_(x, scale=None, shift=None, residual=None, res_scale=None
 
 
 def upsample2x_add_(fine, coarse):
-    """fine += nearest-x2(coarse), in place, channels-last fp32 (FPN top-down step)"""
+    """fine += nearest-x2(coarse), in place, channels-last fp32 / bf16 (FPN top-down step)"""
     _require_gpu(fine, 'fine')
     B, Cn, H, W = fine.shape
-    _lib.check(_lib.lib().ia_upsample2x_add_nhwc(_ptr(fine), _ptr(coarse), B, H, W,
-                                                 int(coarse.shape[2]), int(coarse.shape[3]), Cn,
-                                                 _stream()), 'ia_upsample2x_add_nhwc')
+    vec = 4 if fine.dtype == torch.float32 else 8
+    if fine.dtype not in (torch.float32, torch.bfloat16) or coarse.dtype != fine.dtype or Cn % vec \
+            or not fine.is_contiguous(memory_format=torch.channels_last) \
+            or not coarse.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('upsample2x_add_ needs channels-last fp32 / bf16 tensors of one dtype, '
+                        'C % 4 (fp32) / C % 8 (bf16) == 0')
+    _lib.check(_lib.lib().ia_upsample2x_add_nhwc_dt(_ptr(fine), _ptr(coarse), _dtype_code(fine), B, H, W,
+                                                    int(coarse.shape[2]), int(coarse.shape[3]), Cn,
+                                                    _stream()), 'ia_upsample2x_add_nhwc_dt')
     return fine
 
 
 def affine_relu_maxpool(x, scale, shift):
-    """relu(x * scale + shift) followed by MaxPool2d(3, 2, 1) on a channels-last fp32 tensor"""
+    """relu(x * scale + shift) followed by MaxPool2d(3, 2, 1) on a channels-last fp32 / bf16 tensor
+    (scale / shift fp32)"""
     _require_gpu(x, 'x')
     B, Cn, H, W = x.shape
-    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) or Cn % 4:
-        raise TypeError('affine_relu_maxpool needs a channels-last fp32 tensor, C % 4 == 0')
-    out = torch.empty((B, Cn, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32,
+    vec = 4 if x.dtype == torch.float32 else 8
+    if x.dtype not in (torch.float32, torch.bfloat16) or Cn % vec \
+            or not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('affine_relu_maxpool needs a channels-last fp32 / bf16 tensor, '
+                        'C % 4 (fp32) / C % 8 (bf16) == 0')
+    scale, shift = scale.float().contiguous(), shift.float().contiguous()
+    out = torch.empty((B, Cn, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype,
                       device=x.device, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().ia_affine_relu_maxpool_nhwc(_ptr(x), _ptr(scale), _ptr(shift), B, H, W, Cn,
-                                                      _ptr(out), _stream()),
-               'ia_affine_relu_maxpool_nhwc')
+    _lib.check(_lib.lib().ia_affine_relu_maxpool_nhwc_dt(_ptr(x), _dtype_code(x), _ptr(scale), _ptr(shift),
+                                                         B, H, W, Cn, _ptr(out), _stream()),
+               'ia_affine_relu_maxpool_nhwc_dt')
     return out
 
 

@@ -91,17 +91,21 @@ def test_nhwc_to_nchw_and_channels_last_epilogue(shape, dtype):
         assert c.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, c)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(2, 64, 400, 672), (1, 64, 37, 53), (3, 8, 5, 4), (2, 16, 1, 1)])
-def test_affine_relu_maxpool_matches_torch(shape):
+def test_affine_relu_maxpool_matches_torch(shape, dtype):
+    """bf16: fp32 arithmetic, ONE rounding at the end == eager's affine (rounded) -> ReLU -> max-pool
+    on bf16 values, because rounding and ReLU are monotonic"""
     from iouaware import ops
     g = torch.Generator(device='cuda').manual_seed(1)
-    x = torch.randn(*shape, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(*shape, device='cuda', generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
     s = torch.randn(shape[1], device='cuda', generator=g)        # negative scales included
     t = torch.randn(shape[1], device='cuda', generator=g)
     got = ops.affine_relu_maxpool(x, s, t)
-    want = torch.nn.functional.max_pool2d(torch.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)),
-                                          3, 2, 1)
-    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    aff = (x.float() * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)).to(dtype)
+    want = torch.nn.functional.max_pool2d(torch.relu(aff), 3, 2, 1)
+    assert got.dtype == dtype and got.shape == want.shape
+    assert got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
 
 
@@ -134,8 +138,11 @@ def test_upsample2x_add_matches_torch():
         coarse = torch.randn(B, C_, Hc, Wc, device='cuda', generator=g).contiguous(
             memory_format=torch.channels_last)
         want = fine + torch.nn.functional.interpolate(coarse, scale_factor=2, mode='nearest')
+        fb, cb = fine.to(torch.bfloat16), coarse.to(torch.bfloat16)          # still channels-last
+        want_b = fb + torch.nn.functional.interpolate(cb, scale_factor=2, mode='nearest')
         got = ops.upsample2x_add_(fine, coarse)
         assert got.data_ptr() == fine.data_ptr() and torch.equal(got, want)
+        assert torch.equal(ops.upsample2x_add_(fb, cb), want_b)
 
 
 def test_linear_bias_act_bf16():
