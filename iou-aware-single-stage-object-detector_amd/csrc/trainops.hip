@@ -75,11 +75,16 @@ __global__ __launch_bounds__(256) void k_wino_weight_grad(WinoWeightGradArgs a)
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) t[r][c] = 0.0;
+    // the 36 loads first: next to their use they compile to load + s_waitcnt vmcnt(0) each,
+    // 36 dependent round trips (17 us per launch for a 256 x 256 weight)
+    float du[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) du[k] = a.du[(long)k * total + idx];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double v = (double)a.du[(long)(k * 6 + c) * total + idx];
+            const double v = (double)du[k * 6 + c];
 #pragma unroll
             for (int r = 0; r < 3; ++r) t[r][c] += a.G[k][r] * v;
         }
@@ -170,9 +175,18 @@ __global__ __launch_bounds__(256) void k_colsum_finish(ReluColsumArgs a)
     const int t = threadIdx.x, ql = t & 15, rl = t >> 4;
     const int cb = blockIdx.x, q = cb * 16 + ql, qn = a.n >> 2;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = rl; k < a.S; k += 16) {
-        const float4 w = *reinterpret_cast<const float4 *>(a.partial + ((long)cb * a.S + k) * 64 + 4 * ql);
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    // eight partial rows requested at a time (clamped addresses), added in the same fixed order:
+    // one load per iteration compiled to load + s_waitcnt, up to 32 dependent round trips
+    for (int k0 = rl; k0 < a.S; k0 += 16 * 8) {
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 16 * u;
+            w[u] = *reinterpret_cast<const float4 *>(a.partial + ((long)cb * a.S + (k < a.S ? k : a.S - 1)) * 64 + 4 * ql);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 16 * u < a.S) { v.x += w[u].x; v.y += w[u].y; v.z += w[u].z; v.w += w[u].w; }
     }
     red[t] = v;
     __syncthreads();
