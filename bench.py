@@ -255,23 +255,19 @@ TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_t
 TRAIN_BATCH = 4                           # imgs_per_gpu of the reference's 4-GPU config (:78)
 
 
-def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels_last=False,
-                 fuse=True):
-    """BASELINE config 5, one GPU: whole training iterations of R-50 IoU-aware RetinaNet at
-    800x1344, batch 4, fp32 -- forward, device target assignment + all-levels loss kernels,
-    backward, gradient clipping, SGD (reference mmdet/apis/train.py:38-45, optimizer_config of
-    the configs).  Gradient all-reduce is not part of a single-GPU measurement."""
-    from iouaware.train import build_optimizer, train_step
+def train_state(device, find=False, channels_last=False, fuse=True, seed=0):
+    """model, optimizer and one synthetic batch of a BASELINE config 5 training iteration"""
+    from iouaware.train import build_optimizer
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import synth
     # MIOpen immediate mode: find mode times every candidate of every forward / backward-data /
     # backward-weight convolution in a fresh process (~8 minutes here) for ~7 % more img/s
     torch.backends.cudnn.benchmark = bool(find)
-    torch.manual_seed(0)
+    torch.manual_seed(0)                      # the same initial weights on every rank
     model = iouaware.build_detector(ConfigDict(MODEL), train_cfg=ConfigDict(TRAIN_CFG),
                                     test_cfg=ConfigDict(TEST_CFG)).to(device).train()
     opt = build_optimizer(model, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=0.0001))
-    g = torch.Generator(device=device).manual_seed(7)
+    g = torch.Generator(device=device).manual_seed(7 + seed)
     img = torch.randn(TRAIN_BATCH, 3, PAD_H, PAD_W, device=device, generator=g)
     if fuse:
         # bottlenecks / FPN: one autograd node per convolution on the GEMM / Winograd kernels,
@@ -282,10 +278,20 @@ def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels
     if channels_last:
         model = model.to(memory_format=torch.channels_last)
         img = img.contiguous(memory_format=torch.channels_last)
-    gts, gls = synth.train_targets(5, TRAIN_BATCH, IMG_H, IMG_W, max_gt=20)
+    gts, gls = synth.train_targets(5 + seed, TRAIN_BATCH, IMG_H, IMG_W, max_gt=20)
     gtb = [torch.from_numpy(x).to(device) for x in gts]
     gtl = [torch.from_numpy(x).to(device) for x in gls]
-    ms = metas(TRAIN_BATCH)
+    return model, opt, img, metas(TRAIN_BATCH), gtb, gtl
+
+
+def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels_last=False,
+                 fuse=True):
+    """BASELINE config 5, one GPU: whole training iterations of R-50 IoU-aware RetinaNet at
+    800x1344, batch 4, fp32 -- forward, device target assignment + all-levels loss kernels,
+    backward, gradient clipping, SGD (reference mmdet/apis/train.py:38-45, optimizer_config of
+    the configs).  Gradient all-reduce is not part of a single-GPU measurement."""
+    from iouaware.train import train_step
+    model, opt, img, ms, gtb, gtl = train_state(device, find=find, channels_last=channels_last, fuse=fuse)
     clip = dict(max_norm=35, norm_type=2)
     for _ in range(warmup):
         lv = train_step(model, opt, img, ms, gtb, gtl, grad_clip=clip)
@@ -421,6 +427,8 @@ CONFIGS = {
     'x101-64x4d': ('config 4: IoU-aware RetinaNet X-101-64x4d-FPN fp32, batch 8, grouped 3x3 '
                    'convolutions on the MFMA kernel (csrc/gconv.hip)',
                    dict(type='ResNeXt', depth=101, groups=64, base_width=4), 8, 'float32'),
+    'r50-train': ('config 5: IoU-aware RetinaNet R-50-FPN training step (HIP target / loss kernels), '
+                  'batch 4 per GPU, data-parallel', {}, 4, 'float32'),
 }
 
 
@@ -574,6 +582,44 @@ def stage_traffic():
         return None
 
 
+def main_train(args, cfg_name, world, rank, local_rank, device, sync, barrier, rccl_ranks,
+               rank_devices, launched_by):
+    """--config r50-train: BASELINE config 5 as the measured job -- whole training iterations
+    (forward, device target assignment + all-levels loss kernels, backward, gradient averaging,
+    clipping, SGD), one rank per GPU, every rank its own synthetic batch, gradients averaged by
+    DistributedDataParallel's bucketed all-reduce on RCCL overlapped with backward
+    (iouaware/train.py; reference mmdet/apis/train.py:38-45, core/utils/dist_utils.py:46-57)."""
+    from iouaware.train import train_step, wrap_ddp
+    model, opt, img, ms, gtb, gtl = train_state(device, find=args.train_find, seed=rank)
+    net = wrap_ddp(model, device_ids=[local_rank]) if world > 1 else model
+    clip = dict(max_norm=35, norm_type=2)
+    last = {}
+
+    def step():
+        last['log'] = train_step(net, opt, img, ms, gtb, gtl, grad_clip=clip)
+    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN',
+            'value': round(TRAIN_BATCH * world * args.steps / elapsed, 3), 'unit': 'img/s',
+            'n_gpus': world, 'rccl_ranks': rccl_ranks, 'rank_devices': rank_devices,
+            'launched_by': launched_by, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE %s; 3x800x1344, random-init weights, fwd + HIP targets / '
+                                   'losses + bwd + gradient all-reduce (DDP buckets on RCCL) + clip + '
+                                   'SGD' % cfg_name,
+                       'global_batch': TRAIN_BATCH * world, 'parallelism': 'dp%d' % world,
+                       'miopen_find_mode': bool(args.train_find),
+                       'loss': round(float(last['log']['loss']), 4)},
+            'roofline': None, 'cpu_baseline': None,
+            'note': 'roofline of the loss kernels: DESIGN.md section 4 / profiles/r03_train_pmc.json '
+                    '(k_focal_nhwc fwd 0.70, bwd 0.81 of the HBM peak)'}))
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=None,
@@ -657,6 +703,9 @@ def main():
     ops.gemm_tuning('all')          # library GEMMs: time every supporting kernel per shape (+2 %)
 
     cfg_name, backbone, batch, dtype_name = CONFIGS[args.config]
+    if args.config == 'r50-train':
+        return main_train(args, cfg_name, world, rank, local_rank, device, sync, barrier,
+                          rccl_ranks, rank_devices, launched_by)
     dtype = getattr(torch, dtype_name)
     headline = args.config == 'r50'
     model = build_model(device, fuse=not args.no_fuse, channels_last=not args.nchw,

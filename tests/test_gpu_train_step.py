@@ -67,3 +67,57 @@ def test_build_optimizer_fused_sgd_equals_foreach_sgd():
             o.step()
     for p, q in zip(a.parameters(), b.parameters()):
         assert float((p - q).abs().max()) <= 1e-6 * max(float(q.abs().max()), 1e-12)
+
+
+def test_ddp_wrapped_fused_training_step_matches_unwrapped():
+    """`bench.py --config r50-train` at N > 1 wraps the model in DistributedDataParallel (RCCL).  A
+    one-rank RCCL group exercises the same reducer / bucket hooks on this library's autograd nodes
+    (folded-BN GEMM / Winograd convolutions, fused head losses): the wrapped step must produce the
+    gradients and the update of the plain step."""
+    import copy
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    from iouaware.train import build_optimizer, train_step
+    import bench
+    from test_host_targets import TRAIN_CFG
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(bench.free_port()))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        a = iouaware.build_detector(ConfigDict(bench.MODEL), train_cfg=TRAIN_CFG,
+                                    test_cfg=ConfigDict(bench.TEST_CFG)).cuda().train()
+        b = copy.deepcopy(a)
+        B, ph, pw = 2, 256, 320
+        g = torch.Generator(device='cuda').manual_seed(3)
+        img = torch.randn(B, 3, ph, pw, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+        gts, gls = synth.train_targets(11, B, ph, pw, max_gt=5)
+        gtb = [torch.from_numpy(x).cuda() for x in gts]
+        gtl = [torch.from_numpy(x).cuda() for x in gls]
+        metas = [synth.img_meta(ph, pw, ph, pw) for _ in range(B)]
+        out = []
+        for m, wrap in ((a, False), (b, True)):
+            fuse_inference(m, winograd=True, train=True)
+            m = m.to(memory_format=torch.channels_last)
+            opt = build_optimizer(m, dict(type='SGD', lr=0.005, momentum=0.9, weight_decay=0.0001))
+            net = DistributedDataParallel(m, device_ids=[0], broadcast_buffers=False) if wrap else m
+            for _ in range(2):
+                lv = train_step(net, opt, img, metas, gtb, gtl, grad_clip=dict(max_norm=35, norm_type=2))
+            out.append((lv, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                        {n: p.detach().clone() for n, p in m.named_parameters()}))
+        (la, ga, pa), (lb, gb, pb) = out
+        assert set(ga) == set(gb) and len(ga) > 100
+        assert abs(la['loss'] - lb['loss']) < 1e-4 * abs(la['loss'])
+        for n in ga:                              # library GEMMs / convolutions are not bit-reproducible
+            d = float((ga[n] - gb[n]).norm()), float(ga[n].norm())
+            assert d[0] <= 2e-3 * d[1] + 1e-7, (n, d)
+        for n in pa:
+            assert float((pa[n] - pb[n]).abs().max()) <= 1e-4 * float(pa[n].abs().max()) + 1e-7, n
+    finally:
+        dist.destroy_process_group()
