@@ -318,11 +318,12 @@ def test_training_iteration_vs_the_reference(route, golden_dir):
     assert abs(float(total.detach().sum()) - float(f['total'])) <= 1e-4 * float(f['total'])
     grads = {k: p.grad for k, p in model.named_parameters()}
     assert sorted(k for k, p in model.named_parameters() if not p.requires_grad) == sorted(f['frozen'].tolist())
-    # Bounds = 4-5 x what MI355X measures (profiles/r03_train_parity_report.txt: norms 6.0e-5 /
-    # 6.7e-5, sampled entries 2.5e-4 / 8.1e-4 on the fused / module route): the gradients go
-    # through ~60 convolutions whose fp32 sums are reassociated (Winograd, split-K GEMMs); a
-    # flat 5e-3 / 1e-2 (round 2) would have hidden a 30-fold regression
-    NORM_TOL, SAMPLED_TOL = 3e-4, 3e-3
+    # Bounds = 3-4 x the worst MI355X measures over repeated runs (the library GEMM / convolution
+    # picks differ from run to run; profiles/r03_train_parity_report.txt: norms 1.2e-4 ... 1.7e-4,
+    # sampled entries 5.8e-4 ... 8.7e-4 on the fused / module route): the gradients go through
+    # ~60 convolutions whose fp32 sums are reassociated (Winograd, split-K GEMMs); a flat
+    # 5e-3 / 1e-2 (round 2) would have hidden a 10-fold regression
+    NORM_TOL, SAMPLED_TOL = 5e-4, 3e-3
     worst = worst_s = 0.0
     worst_name = ''
     for name, want in zip(f['grad_names'].tolist(), f['grad_norms']):
