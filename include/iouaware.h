@@ -567,6 +567,19 @@ int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W
 int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, int H, int W, int Hc,
                               int Wc, int C, void *stream);
 
+/* ------------------------------------------------------------------ bf16 3x3 convolution
+ * 3x3 / stride 1 / pad 1 convolution + bias (+ReLU) on bf16 channels-last tensors, fp32
+ * accumulation: the tower / FPN-output ConvModule of BASELINE config 3 (reference
+ * mmdet/models/utils/conv_module.py:149-163, iou_aware_retina_head.py:171-219) as an implicit GEMM
+ * on v_mfma_f32_32x32x16_bf16 (csrc/conv3x3_bf16.hip).  Cin % 32 == 0, Cout % 256 == 0.
+ * ia_conv3x3_bf16_pack: weights (Cout, 3, 3, Cin) bf16 (= a channels-last (Cout, Cin, 3, 3)
+ * tensor) -> the kernel's layout, ia_conv3x3_bf16_packed_bytes(Cin, Cout) bytes, once per model.
+ * x (B, H, W, Cin), y (B, H, W, Cout) bf16; bias (Cout) fp32 or NULL.                              */
+size_t ia_conv3x3_bf16_packed_bytes(int Cin, int Cout);
+int ia_conv3x3_bf16_pack(const void *w, int Cin, int Cout, void *wp, void *stream);
+int ia_conv3x3_bf16_nhwc(const void *x, const void *wp, const float *bias, int relu, int B, int H, int W,
+                         int Cin, int Cout, void *y, void *stream);
+
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the
  * device implementation bit-for-bit: op 0 exp, 1 log, 2 sigmoid, 3 sqrt,

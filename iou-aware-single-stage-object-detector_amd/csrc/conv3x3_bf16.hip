@@ -1,0 +1,303 @@
+// 3x3 / stride 1 / pad 1 convolution on bf16 channels-last tensors, fp32 accumulation, bias (+ReLU)
+// epilogue: the head-tower / FPN-output shape of BASELINE config 3 (R-101 bf16, reference
+// iou_aware_retina_head.py:171-219 `ConvModule(256, 256, 3, padding=1)`, conv_module.py:149-163).
+// An implicit GEMM on v_mfma_f32_32x32x16_bf16: M = the pixels of a spatial tile, N = 256 output
+// channels, K = 9 taps x Cin.
+//
+//  * A workgroup (8 wavefronts, 2 x 4) owns a TH x TW pixel tile (TH * TW <= 256; the tile shape is
+//    picked per feature map so that the tiles cover it with little overhang: 10 x 24 for 100 x 168,
+//    9 x 28 for 50 x 84 ...) and 256 output channels; a wavefront 128 pixels x 64 channels
+//    = 4 x 2 accumulator blocks of 32 x 32.
+//  * K loop: Cin in chunks of 32.  The (TH + 2) x (TW + 2) halo patch of a chunk goes to LDS ONCE
+//    and serves all nine taps as shifted windows (a tap only moves the wavefront's read offset):
+//    1.3 reads of the activation instead of an im2col GEMM's 9.  The weights of (chunk, tap) --
+//    256 x 32, packed contiguously by ia_conv3x3_bf16_pack -- are double-buffered in LDS; the next
+//    tile's global loads are issued before the MFMAs of the current one.
+//  * LDS rows (a pixel's / an output channel's 32 k-values = 64 bytes) are padded to 80 bytes: the
+//    16 lanes of a ds_read_b128 group then start in 16 different 16-byte bank slots.
+//  * Epilogue from the accumulators: + bias, ReLU, round to bf16; neighbouring lanes hold
+//    neighbouring output channels of one pixel, so lane pairs swap one value (DPP) and store
+//    4 bytes each, 64-byte runs per pixel.
+#include <string.h>
+#include "ia_internal.hpp"
+#include "ia_math.hpp"
+
+namespace ia {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kCvThreads = 512;
+constexpr int kCvBK = 32;                 // input channels per K step
+constexpr int kCvRow = 80;                // bytes per LDS row (64 of data)
+constexpr int kCvMaxPatch = 352;          // (TH + 2) * (TW + 2) <= this
+constexpr int kCvBN = 256;
+
+struct Conv3Args {
+    const uint16_t *x;                    // (B, H, W, Cin) bf16
+    const uint16_t *wp;                   // packed weights [Cout / 256][Cin / 32][9][256][32]
+    const float *bias;                    // (Cout) or NULL
+    uint16_t *y;                          // (B, H, W, Cout)
+    int32_t B, H, W, Cin, Cout, relu;
+    int32_t TH, TW, tiles_y, tiles_x;
+};
+
+__device__ __forceinline__ uint32_t bf16_rne(float f)
+{
+    uint32_t u = to_bits(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[kCvMaxPatch * kCvRow];
+    __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kCvBN * kCvRow];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 2, wn = wv & 3;                  // 2 x 4 wavefronts
+    int t = blockIdx.x;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int nt = blockIdx.y;
+    const int y0 = tyi * a.TH, x0 = txi * a.TW;
+    const int PW = a.TW + 2, npix = (a.TH + 2) * PW, tile_px = a.TH * a.TW;
+    const int nchunk = a.Cin / kCvBK, nsteps = nchunk * 9;
+
+    // ---- this lane's four A rows (pixels) as byte offsets into the patch (tap (0,0) corner)
+    int a_off[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        int m = wm * 128 + mb * 32 + (lane & 31);
+        m = m < tile_px ? m : tile_px - 1;                // idle rows read a valid address
+        const int ty = m / a.TW, tx = m - ty * a.TW;
+        a_off[mb] = (ty * PW + tx) * kCvRow + (lane >> 5) * 16;
+    }
+    const int b_off = (wn * 64 + (lane & 31)) * kCvRow + (lane >> 5) * 16;
+
+    // ---- global -> register staging (plain scalars and macros: arrays captured by a lambda went
+    // to scratch memory).  Weights of step s + 2 are requested at the start of step s and stored to
+    // LDS at the end of step s + 1: two steps of MFMA time to arrive; the halo patch of the next
+    // chunk is requested three taps ahead.
+    const uint16_t *xb = a.x + (size_t)b * a.H * a.W * a.Cin;
+    const uint16_t *wbase = a.wp + (size_t)nt * nchunk * 9 * (kCvBN * kCvBK) + tid * 8;
+    // patch pieces of this thread: p = u * 512 + tid -> pixel p >> 2, 16-byte part p & 3
+    const uint16_t *pa0, *pa1, *pa2;
+    bool in0, in1, in2, on0, on1, on2;
+#define CV_PIECE(u, PA, IN, ON)                                                                     \
+    {                                                                                               \
+        int p = u * kCvThreads + tid;                                                               \
+        ON = p < npix * 4;                                                                          \
+        p = ON ? p : 0;                                                                             \
+        const int px = p >> 2, part = p & 3;                                                        \
+        const int py = px / PW, pxx = px - py * PW;                                                 \
+        const int iy = y0 + py - 1, ix = x0 + pxx - 1;                                              \
+        IN = ON && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                      \
+        const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix); \
+        PA = xb + ((size_t)cy * a.W + cx) * a.Cin + part * 8;                                       \
+    }
+    CV_PIECE(0, pa0, in0, on0)
+    CV_PIECE(1, pa1, in1, on1)
+    CV_PIECE(2, pa2, in2, on2)
+#undef CV_PIECE
+    // (an AND with a per-piece mask: `in ? value : zero` on a 128-bit value became a table in scratch)
+    const uint32_t mk0 = in0 ? 0xffffffffu : 0u, mk1 = in1 ? 0xffffffffu : 0u, mk2 = in2 ? 0xffffffffu : 0u;
+    unsigned char *sa0 = s_a + (tid >> 2) * kCvRow + (tid & 3) * 16;
+    unsigned char *sa1 = sa0 + (kCvThreads >> 2) * kCvRow, *sa2 = sa1 + (kCvThreads >> 2) * kCvRow;
+    const int sb_off = (tid >> 2) * kCvRow + (tid & 3) * 16;               // + 128 rows for the second piece
+    uint4 ra0, ra1, ra2, rx0, rx1, ry0, ry1;
+#define CV_LOAD_A(chunk)                                                                            \
+    {                                                                                               \
+        ra0 = *reinterpret_cast<const uint4 *>(pa0 + (chunk) * kCvBK);                              \
+        ra1 = *reinterpret_cast<const uint4 *>(pa1 + (chunk) * kCvBK);                              \
+        ra2 = *reinterpret_cast<const uint4 *>(pa2 + (chunk) * kCvBK);                              \
+    }
+#define CV_STORE_A()                                                                                \
+    {                                                                                               \
+        /* the padding select happens HERE: at the load it would be the load's first use, i.e. a  \
+           full memory round trip in the middle of the K loop */                                    \
+        if (on0) *reinterpret_cast<uint4 *>(sa0) = make_uint4(ra0.x & mk0, ra0.y & mk0, ra0.z & mk0, ra0.w & mk0); \
+        if (on1) *reinterpret_cast<uint4 *>(sa1) = make_uint4(ra1.x & mk1, ra1.y & mk1, ra1.z & mk1, ra1.w & mk1); \
+        if (on2) *reinterpret_cast<uint4 *>(sa2) = make_uint4(ra2.x & mk2, ra2.y & mk2, ra2.z & mk2, ra2.w & mk2); \
+    }
+#define CV_LOAD_B(step, R0, R1)                                                                     \
+    {                                                                                               \
+        const uint16_t *src = wbase + (size_t)(step) * (kCvBN * kCvBK);                             \
+        R0 = *reinterpret_cast<const uint4 *>(src);                                                 \
+        R1 = *reinterpret_cast<const uint4 *>(src + kCvThreads * 8);                                \
+    }
+#define CV_STORE_B(buf, R0, R1)                                                                     \
+    {                                                                                               \
+        *reinterpret_cast<uint4 *>(s_b[buf] + sb_off) = R0;                                         \
+        *reinterpret_cast<uint4 *>(s_b[buf] + sb_off + 128 * kCvRow) = R1;                          \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    CV_LOAD_A(0)
+    CV_LOAD_B(0, rx0, rx1)
+    CV_STORE_A()
+    CV_STORE_B(0, rx0, rx1)
+    CV_LOAD_B(nsteps > 1 ? 1 : 0, rx0, rx1)                // set X holds B(s + 1) at the start of step s
+    __syncthreads();
+
+    // One step: MFMAs of (chunk, TAP) from the patch and s_b[buf]; set X (weights of step + 1) goes
+    // to s_b[buf ^ 1] at the end, set Y receives the weights of step + 2.  Branch-free on purpose:
+    // every load / LDS store is unconditional (indices clamped at the end of the K loop), so the
+    // compiler can count the outstanding loads and wait for exactly the older set -- behind a
+    // conditional load it falls back to s_waitcnt vmcnt(0), which turns the two-step prefetch
+    // into none.
+#define CV_STEP(TAP, X0, X1, Y0, Y1)                                                                \
+    {                                                                                               \
+        constexpr int dy = (TAP) / 3, dx = (TAP) - dy * 3;                                          \
+        const int step = step0 + (TAP);                                                             \
+        const int s2 = step + 2 < nsteps ? step + 2 : nsteps - 1;                                   \
+        CV_LOAD_B(s2, Y0, Y1)                                                                       \
+        if ((TAP) == 5) CV_LOAD_A(chunk + 1 < nchunk ? chunk + 1 : chunk)                           \
+        const unsigned char *ab = s_a + (dy * PW + dx) * kCvRow;                                    \
+        const unsigned char *bb = s_b[0] + ((step & 1) ? kCvBN * kCvRow : 0) + b_off;               \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
+            bf16x8 fa[4], fb[2];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+                fa[i] = *reinterpret_cast<const bf16x8 *>(ab + a_off[i] + kk * 32);                 \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                fb[j] = *reinterpret_cast<const bf16x8 *>(bb + j * 32 * kCvRow + kk * 32);          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0); \
+        }                                                                                           \
+        {                                                                                           \
+            unsigned char *dst = s_b[0] + ((step & 1) ? 0 : kCvBN * kCvRow) + sb_off;               \
+            *reinterpret_cast<uint4 *>(dst) = X0;                                                   \
+            *reinterpret_cast<uint4 *>(dst + 128 * kCvRow) = X1;                                    \
+        }                                                                                           \
+        if ((TAP) == 8) {                                                                           \
+            __syncthreads();                               /* every wavefront is done with the patch */ \
+            CV_STORE_A()                                                                            \
+        }                                                                                           \
+        __syncthreads();                                                                            \
+    }
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const int step0 = chunk * 9;
+        CV_STEP(0, rx0, rx1, ry0, ry1)
+        CV_STEP(1, ry0, ry1, rx0, rx1)
+        CV_STEP(2, rx0, rx1, ry0, ry1)
+        CV_STEP(3, ry0, ry1, rx0, rx1)
+        CV_STEP(4, rx0, rx1, ry0, ry1)
+        CV_STEP(5, ry0, ry1, rx0, rx1)
+        CV_STEP(6, rx0, rx1, ry0, ry1)
+        CV_STEP(7, ry0, ry1, rx0, rx1)
+        CV_STEP(8, rx0, rx1, ry0, ry1)
+        // nine steps: the sets have swapped roles
+        { const uint4 t0 = rx0, t1 = rx1; rx0 = ry0; rx1 = ry1; ry0 = t0; ry1 = t1; }
+    }
+#undef CV_STEP
+#undef CV_LOAD_A
+#undef CV_STORE_A
+#undef CV_LOAD_B
+#undef CV_STORE_B
+
+    // ---- epilogue: C block (i, j): column n = lane & 31, row m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nt * kCvBN + wn * 64 + j * 32 + (lane & 31);
+        const float bz = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float v0 = acc[i][j][r] + bz, v1 = acc[i][j][r + 1] + bz;
+                if (a.relu) { v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; }
+                // even lane keeps row r and takes the odd neighbour's row-r value (channel n + 1);
+                // odd lane keeps row r + 1 and takes the even neighbour's (channel n - 1)
+                const float give = odd ? v0 : v1;
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                const int rr = odd ? r + 1 : r;
+                const int m = wm * 128 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                const uint32_t lo = bf16_rne(odd ? got : v0), hi = bf16_rne(odd ? v1 : got);
+                if (m < tile_px) {
+                    const int ty = m / a.TW, tx = m - ty * a.TW;
+                    const int oy = y0 + ty, ox = x0 + tx;
+                    if (oy < a.H && ox < a.W)
+                        *reinterpret_cast<uint32_t *>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.Cout + (n - odd)) = lo | (hi << 16);
+                }
+            }
+        }
+    }
+}
+
+// weights (Cout, 3, 3, Cin) bf16 -> [Cout / 256][Cin / 32][9][256][32]
+__global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_t *wp, int Cin, int Cout)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)Cout * 9 * Cin;
+    if (idx >= total) return;
+    const int k = (int)(idx % kCvBK);
+    int64_t r = idx / kCvBK;
+    const int n = (int)(r % kCvBN); r /= kCvBN;
+    const int tap = (int)(r % 9); r /= 9;
+    const int nchunk = Cin / kCvBK;
+    const int chunk = (int)(r % nchunk);
+    const int nt = (int)(r / nchunk);
+    wp[idx] = w[(((size_t)(nt * kCvBN + n) * 9) + tap) * Cin + chunk * kCvBK + k];
+}
+
+// tile shape for an H x W map: TH * TW <= 256, patch <= kCvMaxPatch, least overhang
+static void conv3_tile_shape(int H, int W, int &TH, int &TW)
+{
+    double best = -1.0;
+    TH = 16; TW = 16;
+    for (int tw = 4; tw <= 64; ++tw) {
+        for (int th = 2; th <= 64; ++th) {
+            if (th * tw > 256 || (th + 2) * (tw + 2) > kCvMaxPatch) continue;
+            const int64_t ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+            // useful pixels per 256-row tile
+            const double eff = (double)H * W / ((double)ty * tx * 256.0);
+            if (eff > best + 1e-9) { best = eff; TH = th; TW = tw; }
+        }
+    }
+}
+
+}  // namespace ia
+
+extern "C" {
+
+size_t ia_conv3x3_bf16_packed_bytes(int Cin, int Cout) { return (size_t)Cout * 9 * Cin * 2; }
+
+int ia_conv3x3_bf16_pack(const void *w, int Cin, int Cout, void *wp, void *stream)
+{
+    if (!w || !wp || Cin < 32 || (Cin % ia::kCvBK) || Cout < 256 || (Cout % ia::kCvBN)) return IA_E_ARG;
+    const int64_t total = (int64_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(ia::k_conv3x3_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint16_t *>(w), static_cast<uint16_t *>(wp), Cin, Cout);
+    return ia::hip_status(hipGetLastError());
+}
+
+int ia_conv3x3_bf16_nhwc(const void *x, const void *wp, const float *bias, int relu, int B, int H, int W,
+                         int Cin, int Cout, void *y, void *stream)
+{
+    if (!x || !wp || !y || B < 1 || H < 1 || W < 1 || Cin < 32 || (Cin % ia::kCvBK) || Cout < 256 ||
+        (Cout % ia::kCvBN))
+        return IA_E_ARG;
+    if (((uintptr_t)x & 15u) || ((uintptr_t)wp & 15u) || ((uintptr_t)y & 3u)) return IA_E_ARG;
+    ia::Conv3Args a;
+    a.x = static_cast<const uint16_t *>(x); a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    ia::conv3_tile_shape(H, W, a.TH, a.TW);
+    a.tiles_y = (H + a.TH - 1) / a.TH; a.tiles_x = (W + a.TW - 1) / a.TW;
+    const int64_t tiles = (int64_t)B * a.tiles_y * a.tiles_x;
+    if (tiles > 2147483647LL) return IA_E_ARG;
+    hipLaunchKernelGGL(ia::k_conv3x3_bf16, dim3((unsigned)tiles, (unsigned)(Cout / ia::kCvBN)), dim3(ia::kCvThreads), 0,
+                       (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
+
+}  // extern "C"

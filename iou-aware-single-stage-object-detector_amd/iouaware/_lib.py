@@ -158,6 +158,9 @@ SIGNATURES = {
     'ia_channel_affine_act_nhwc': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'ia_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i64, _vp]),
     'ia_upsample2x_add_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ia_conv3x3_bf16_packed_bytes': (C.c_size_t, [_i, _i]),
+    'ia_conv3x3_bf16_pack': (_i, [_vp, _i, _i, _vp, _vp]),
+    'ia_conv3x3_bf16_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ia_upsample2x_add_nhwc_dt': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_affine_relu_maxpool_nhwc_dt': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'ia_affine_relu_maxpool_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

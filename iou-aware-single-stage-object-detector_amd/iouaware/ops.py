@@ -546,6 +546,33 @@ def affine_relu_maxpool(x, scale, shift):
     return out
 
 
+def conv3x3_bf16_pack(weight):
+    """(Cout, Cin, 3, 3) weight -> the packed bf16 layout of `conv3x3_bf16` (once per model)"""
+    _require_gpu(weight, 'weight')
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or ci % 32 or co % 256:
+        raise ValueError('conv3x3_bf16 needs a 3x3 kernel, Cin % 32 == 0, Cout % 256 == 0')
+    w = weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()      # (Cout, 3, 3, Cin)
+    wp = torch.empty(co * 9 * ci, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(_lib.lib().ia_conv3x3_bf16_pack(_ptr(w), ci, co, _ptr(wp), _stream()), 'ia_conv3x3_bf16_pack')
+    return wp
+
+
+def conv3x3_bf16(x, wp, bias, cout, relu=False):
+    """3x3 / stride 1 / pad 1 convolution + bias (+ReLU) of a channels-last bf16 tensor on the
+    MFMA implicit-GEMM kernel (csrc/conv3x3_bf16.hip); wp from conv3x3_bf16_pack, bias fp32"""
+    _require_gpu(x, 'x')
+    B, ci, H, W = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('conv3x3_bf16 needs a channels-last bf16 tensor')
+    if wp.numel() != cout * 9 * ci:
+        raise ValueError('packed weight does not match (Cin, Cout)')
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().ia_conv3x3_bf16_nhwc(_ptr(x), _ptr(wp), _ptr(bias), int(bool(relu)), B, H, W, ci, cout,
+                                               _ptr(y), _stream()), 'ia_conv3x3_bf16_nhwc')
+    return y
+
+
 _LT_WS_BYTES = 64 << 20
 
 

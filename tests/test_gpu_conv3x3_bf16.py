@@ -1,0 +1,40 @@
+"""GPU: the bf16 3x3 implicit-GEMM convolution (csrc/conv3x3_bf16.hip) against torch.  Reference:
+the same convolution in fp64 on the bf16-rounded inputs; the kernel accumulates in fp32 and rounds
+the result to bf16 once, so |error| <= 2^-9 |y| (one bf16 rounding) + the fp32 accumulation noise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('B,H,W,ci,co,relu,bias', [
+    (1, 7, 11, 32, 256, False, False),        # one partial tile
+    (2, 13, 21, 64, 256, True, True),
+    (1, 25, 42, 256, 256, True, True),        # P5
+    (2, 50, 84, 256, 256, True, True),        # P4: 9 x 28 tiles
+    (1, 100, 168, 256, 256, False, True),     # P3: 10 x 24 tiles
+    (1, 33, 17, 96, 512, True, True),         # two column blocks, Cin not a power of two
+])
+def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias):
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(H * W + ci)
+    x = torch.randn(B, ci, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, 3, 3, device='cuda', generator=g) * (2.0 / (9 * ci)) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(co, device='cuda', generator=g) if bias else None
+    wp = ops.conv3x3_bf16_pack(w)
+    y = ops.conv3x3_bf16(x, wp, b, co, relu=relu)
+    assert y.shape == (B, co, H, W) and y.dtype == torch.bfloat16
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    want = torch.nn.functional.conv2d(x.double(), w.double(), b.double() if bias else None, 1, 1)
+    if relu:
+        want = want.clamp(min=0)
+    err = (y.double() - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 2e-3 * float(want.abs().max()) * 2.0 ** -8
+    assert bool((err <= tol).all()), (float(err.max()), float(want.abs().max()))
+    # and the framework's own bf16 convolution is not closer than this kernel by more than rounding
+    eager = torch.nn.functional.conv2d(x, w.contiguous(memory_format=torch.channels_last), b.to(torch.bfloat16) if bias else None, 1, 1)
+    if relu:
+        eager = eager.clamp(min=0)
+    e_eager = float((eager.double() - want).pow(2).mean().sqrt())
+    e_mine = float((y.double() - want).pow(2).mean().sqrt())
+    assert e_mine <= 1.2 * e_eager + 1e-6, (e_mine, e_eager)
