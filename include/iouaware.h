@@ -569,16 +569,25 @@ int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, 
 
 /* ------------------------------------------------------------------ bf16 3x3 convolution
  * 3x3 / stride 1 / pad 1 convolution + bias (+ReLU) on bf16 channels-last tensors, fp32
- * accumulation: the tower / FPN-output ConvModule of BASELINE config 3 (reference
+ * accumulation: the tower / output / FPN ConvModules of BASELINE config 3 (reference
  * mmdet/models/utils/conv_module.py:149-163, iou_aware_retina_head.py:171-219) as an implicit GEMM
- * on v_mfma_f32_32x32x16_bf16 (csrc/conv3x3_bf16.hip).  Cin % 32 == 0, Cout % 256 == 0.
- * ia_conv3x3_bf16_pack: weights (Cout, 3, 3, Cin) bf16 (= a channels-last (Cout, Cin, 3, 3)
- * tensor) -> the kernel's layout, ia_conv3x3_bf16_packed_bytes(Cin, Cout) bytes, once per model.
- * x (B, H, W, Cin), y (B, H, W, Cout) bf16; bias (Cout) fp32 or NULL.                              */
-size_t ia_conv3x3_bf16_packed_bytes(int Cin, int Cout);
-int ia_conv3x3_bf16_pack(const void *w, int Cin, int Cout, void *wp, void *stream);
-int ia_conv3x3_bf16_nhwc(const void *x, const void *wp, const float *bias, int relu, int B, int H, int W,
-                         int Cin, int Cout, void *y, void *stream);
+ * on v_mfma_f32_32x32x16_bf16 (csrc/conv3x3_bf16.hip).  One launch covers a list of feature maps
+ * (the pyramid levels the head's weights are shared over) and up to two groups (the cls and the
+ * reg tower: own inputs, weights, outputs).  cin % 32 == 0, cout even (per group).
+ * ia_conv3x3_bf16_pack: weights (groups * cout, 3, 3, cin) bf16 (= a channels-last
+ * (groups * cout, cin, 3, 3) tensor) -> the kernel's layout, ia_conv3x3_bf16_packed_bytes bytes,
+ * once per model.  bias (groups * cout) fp32 or NULL.                                             */
+typedef struct ia_conv3x3_desc {
+    int32_t num_levels, batch, groups;
+    int32_t cin, cout;                    /* channels per group                                   */
+    int32_t x_stride, y_stride;           /* elements between pixels of x / y (>= cin / cout)     */
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS];
+    const void *x[2][IA_MAX_LEVELS];      /* [group][level] -> (batch, H, W, x_stride) bf16, 16-byte aligned */
+    void *y[2][IA_MAX_LEVELS];            /* [group][level] -> (batch, H, W, y_stride) bf16       */
+} ia_conv3x3_desc;
+size_t ia_conv3x3_bf16_packed_bytes(int cin, int cout, int groups);
+int ia_conv3x3_bf16_pack(const void *w, int cin, int cout, int groups, void *wp, void *stream);
+int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float *bias, int relu, void *stream);
 
 /* ------------------------------------------------------------------ self-test
  * Elementwise fp32 math used by the kernels, exposed so tests can pin the

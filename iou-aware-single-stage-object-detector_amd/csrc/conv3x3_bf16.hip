@@ -33,13 +33,18 @@ constexpr int kCvRow = 80;                // bytes per LDS row (64 of data)
 constexpr int kCvMaxPatch = 352;          // (TH + 2) * (TW + 2) <= this
 constexpr int kCvBN = 256;
 
+constexpr int kCvMaxGroups = 2;
+
+// One launch covers a list of feature maps (the pyramid levels of the shared-weight head) and up
+// to two groups (the cls / reg towers: different inputs, weights and outputs, one tile list).
 struct Conv3Args {
-    const uint16_t *x;                    // (B, H, W, Cin) bf16
-    const uint16_t *wp;                   // packed weights [Cout / 256][Cin / 32][9][256][32]
-    const float *bias;                    // (Cout) or NULL
-    uint16_t *y;                          // (B, H, W, Cout)
-    int32_t B, H, W, Cin, Cout, relu;
-    int32_t TH, TW, tiles_y, tiles_x;
+    const uint16_t *x[kCvMaxGroups][IA_MAX_LEVELS];   // (B, H_l, W_l, .) bf16, pixel stride xs
+    uint16_t *y[kCvMaxGroups][IA_MAX_LEVELS];         // (B, H_l, W_l, .) bf16, pixel stride ys
+    const uint16_t *wp;                   // packed weights [groups][ntile][Cin / 32][9][256][32]
+    const float *bias;                    // (groups * Cout) or NULL
+    int32_t L, B, Cin, Cout, xs, ys, relu, ntile;     // Cin / Cout per group; ntile = ceil(Cout / 256)
+    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], TH[IA_MAX_LEVELS], TW[IA_MAX_LEVELS];
+    int32_t tiles_y[IA_MAX_LEVELS], tiles_x[IA_MAX_LEVELS], tile_off[IA_MAX_LEVELS + 1];
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float f)
@@ -55,13 +60,16 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kCvBN * kCvRow];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 2, wn = wv & 3;                  // 2 x 4 wavefronts
-    int t = blockIdx.x;
-    const int txi = t % a.tiles_x; t /= a.tiles_x;
-    const int tyi = t % a.tiles_y;
-    const int b = t / a.tiles_y;
-    const int nt = blockIdx.y;
-    const int y0 = tyi * a.TH, x0 = txi * a.TW;
-    const int PW = a.TW + 2, npix = (a.TH + 2) * PW, tile_px = a.TH * a.TW;
+    int lv = 0;
+    while (lv + 1 < a.L && (int)blockIdx.x >= a.tile_off[lv + 1]) ++lv;   // wavefront-uniform
+    int t = (int)blockIdx.x - a.tile_off[lv];
+    const int H = a.H[lv], W = a.W[lv], TH = a.TH[lv], TW = a.TW[lv];
+    const int txi = t % a.tiles_x[lv]; t /= a.tiles_x[lv];
+    const int tyi = t % a.tiles_y[lv];
+    const int b = t / a.tiles_y[lv];
+    const int grp = (int)blockIdx.y / a.ntile, nt = (int)blockIdx.y - grp * a.ntile;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const int PW = TW + 2, npix = (TH + 2) * PW, tile_px = TH * TW;
     const int nchunk = a.Cin / kCvBK, nsteps = nchunk * 9;
 
     // ---- this lane's four A rows (pixels) as byte offsets into the patch (tap (0,0) corner)
@@ -70,7 +78,7 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     for (int mb = 0; mb < 4; ++mb) {
         int m = wm * 128 + mb * 32 + (lane & 31);
         m = m < tile_px ? m : tile_px - 1;                // idle rows read a valid address
-        const int ty = m / a.TW, tx = m - ty * a.TW;
+        const int ty = m / TW, tx = m - ty * TW;
         a_off[mb] = (ty * PW + tx) * kCvRow + (lane >> 5) * 16;
     }
     const int b_off = (wn * 64 + (lane & 31)) * kCvRow + (lane >> 5) * 16;
@@ -79,8 +87,8 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     // to scratch memory).  Weights of step s + 2 are requested at the start of step s and stored to
     // LDS at the end of step s + 1: two steps of MFMA time to arrive; the halo patch of the next
     // chunk is requested three taps ahead.
-    const uint16_t *xb = a.x + (size_t)b * a.H * a.W * a.Cin;
-    const uint16_t *wbase = a.wp + (size_t)nt * nchunk * 9 * (kCvBN * kCvBK) + tid * 8;
+    const uint16_t *xb = a.x[grp][lv] + (size_t)b * H * W * a.xs;
+    const uint16_t *wbase = a.wp + (size_t)(grp * a.ntile + nt) * nchunk * 9 * (kCvBN * kCvBK) + tid * 8;
     // patch pieces of this thread: p = u * 512 + tid -> pixel p >> 2, 16-byte part p & 3
     const uint16_t *pa0, *pa1, *pa2;
     bool in0, in1, in2, on0, on1, on2;
@@ -92,9 +100,9 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
         const int px = p >> 2, part = p & 3;                                                        \
         const int py = px / PW, pxx = px - py * PW;                                                 \
         const int iy = y0 + py - 1, ix = x0 + pxx - 1;                                              \
-        IN = ON && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                                      \
-        const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix); \
-        PA = xb + ((size_t)cy * a.W + cx) * a.Cin + part * 8;                                       \
+        IN = ON && iy >= 0 && iy < H && ix >= 0 && ix < W;                                      \
+        const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix); \
+        PA = xb + ((size_t)cy * W + cx) * a.xs + part * 8;                                       \
     }
     CV_PIECE(0, pa0, in0, on0)
     CV_PIECE(1, pa1, in1, on1)
@@ -207,8 +215,9 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     const int odd = lane & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = nt * kCvBN + wn * 64 + j * 32 + (lane & 31);
-        const float bz = a.bias ? a.bias[n] : 0.0f;
+        const int n = nt * kCvBN + wn * 64 + j * 32 + (lane & 31);          // channel inside the group
+        const bool n_ok = (n - odd) + 1 < a.Cout;                             // the pair this lane stores (Cout is even)
+        const float bz = (a.bias && n < a.Cout) ? a.bias[grp * a.Cout + n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -223,30 +232,33 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
                 const int m = wm * 128 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
                 const uint32_t lo = bf16_rne(odd ? got : v0), hi = bf16_rne(odd ? v1 : got);
                 if (m < tile_px) {
-                    const int ty = m / a.TW, tx = m - ty * a.TW;
+                    const int ty = m / TW, tx = m - ty * TW;
                     const int oy = y0 + ty, ox = x0 + tx;
-                    if (oy < a.H && ox < a.W)
-                        *reinterpret_cast<uint32_t *>(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.Cout + (n - odd)) = lo | (hi << 16);
+                    if (oy < H && ox < W && n_ok)
+                        *reinterpret_cast<uint32_t *>(a.y[grp][lv] + (((size_t)b * H + oy) * W + ox) * a.ys + (n - odd)) = lo | (hi << 16);
                 }
             }
         }
     }
 }
 
-// weights (Cout, 3, 3, Cin) bf16 -> [Cout / 256][Cin / 32][9][256][32]
-__global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_t *wp, int Cin, int Cout)
+// weights (groups * Cout, 3, 3, Cin) bf16 -> [groups][ceil(Cout / 256)][Cin / 32][9][256][32], output
+// channels beyond Cout zero
+__global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_t *wp, int Cin, int Cout, int groups)
 {
+    const int ntile = (Cout + kCvBN - 1) / kCvBN, nchunk = Cin / kCvBK;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)Cout * 9 * Cin;
+    const int64_t total = (int64_t)groups * ntile * kCvBN * 9 * Cin;
     if (idx >= total) return;
     const int k = (int)(idx % kCvBK);
     int64_t r = idx / kCvBK;
     const int n = (int)(r % kCvBN); r /= kCvBN;
     const int tap = (int)(r % 9); r /= 9;
-    const int nchunk = Cin / kCvBK;
-    const int chunk = (int)(r % nchunk);
-    const int nt = (int)(r / nchunk);
-    wp[idx] = w[(((size_t)(nt * kCvBN + n) * 9) + tap) * Cin + chunk * kCvBK + k];
+    const int chunk = (int)(r % nchunk); r /= nchunk;
+    const int nt = (int)(r % ntile);
+    const int g = (int)(r / ntile);
+    const int co = nt * kCvBN + n;
+    wp[idx] = co < Cout ? w[(((size_t)(g * Cout + co) * 9) + tap) * Cin + chunk * kCvBK + k] : (uint16_t)0;
 }
 
 // tile shape for an H x W map: TH * TW <= 256, patch <= kCvMaxPatch, least overhang
@@ -269,33 +281,52 @@ static void conv3_tile_shape(int H, int W, int &TH, int &TW)
 
 extern "C" {
 
-size_t ia_conv3x3_bf16_packed_bytes(int Cin, int Cout) { return (size_t)Cout * 9 * Cin * 2; }
-
-int ia_conv3x3_bf16_pack(const void *w, int Cin, int Cout, void *wp, void *stream)
+size_t ia_conv3x3_bf16_packed_bytes(int Cin, int Cout, int groups)
 {
-    if (!w || !wp || Cin < 32 || (Cin % ia::kCvBK) || Cout < 256 || (Cout % ia::kCvBN)) return IA_E_ARG;
-    const int64_t total = (int64_t)Cout * 9 * Cin;
+    return (size_t)groups * ((Cout + ia::kCvBN - 1) / ia::kCvBN) * ia::kCvBN * 9 * Cin * 2;
+}
+
+int ia_conv3x3_bf16_pack(const void *w, int Cin, int Cout, int groups, void *wp, void *stream)
+{
+    if (!w || !wp || Cin < 32 || (Cin % ia::kCvBK) || Cout < 2 || (Cout & 1) || groups < 1 ||
+        groups > ia::kCvMaxGroups)
+        return IA_E_ARG;
+    const int64_t total = (int64_t)(ia_conv3x3_bf16_packed_bytes(Cin, Cout, groups) / 2);
     hipLaunchKernelGGL(ia::k_conv3x3_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const uint16_t *>(w), static_cast<uint16_t *>(wp), Cin, Cout);
+                       static_cast<const uint16_t *>(w), static_cast<uint16_t *>(wp), Cin, Cout, groups);
     return ia::hip_status(hipGetLastError());
 }
 
-int ia_conv3x3_bf16_nhwc(const void *x, const void *wp, const float *bias, int relu, int B, int H, int W,
-                         int Cin, int Cout, void *y, void *stream)
+int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float *bias, int relu, void *stream)
 {
-    if (!x || !wp || !y || B < 1 || H < 1 || W < 1 || Cin < 32 || (Cin % ia::kCvBK) || Cout < 256 ||
-        (Cout % ia::kCvBN))
+    if (!d || !wp || d->num_levels < 1 || d->num_levels > IA_MAX_LEVELS || d->batch < 1 || d->groups < 1 ||
+        d->groups > ia::kCvMaxGroups || d->cin < 32 || (d->cin % ia::kCvBK) || d->cout < 2 || (d->cout & 1) ||
+        d->x_stride < d->cin || (d->x_stride & 7) || d->y_stride < d->cout || (d->y_stride & 1))
         return IA_E_ARG;
-    if (((uintptr_t)x & 15u) || ((uintptr_t)wp & 15u) || ((uintptr_t)y & 3u)) return IA_E_ARG;
+    if ((uintptr_t)wp & 15u) return IA_E_ARG;
     ia::Conv3Args a;
-    a.x = static_cast<const uint16_t *>(x); a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
-    a.y = static_cast<uint16_t *>(y);
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
-    ia::conv3_tile_shape(H, W, a.TH, a.TW);
-    a.tiles_y = (H + a.TH - 1) / a.TH; a.tiles_x = (W + a.TW - 1) / a.TW;
-    const int64_t tiles = (int64_t)B * a.tiles_y * a.tiles_x;
-    if (tiles > 2147483647LL) return IA_E_ARG;
-    hipLaunchKernelGGL(ia::k_conv3x3_bf16, dim3((unsigned)tiles, (unsigned)(Cout / ia::kCvBN)), dim3(ia::kCvThreads), 0,
+    memset(&a, 0, sizeof(a));
+    a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
+    a.L = d->num_levels; a.B = d->batch; a.Cin = d->cin; a.Cout = d->cout; a.xs = d->x_stride; a.ys = d->y_stride;
+    a.relu = relu ? 1 : 0; a.ntile = (d->cout + ia::kCvBN - 1) / ia::kCvBN;
+    int64_t tiles = 0;
+    for (int l = 0; l < d->num_levels; ++l) {
+        if (d->H[l] < 1 || d->W[l] < 1) return IA_E_ARG;
+        a.H[l] = d->H[l]; a.W[l] = d->W[l];
+        ia::conv3_tile_shape(a.H[l], a.W[l], a.TH[l], a.TW[l]);
+        a.tiles_y[l] = (a.H[l] + a.TH[l] - 1) / a.TH[l]; a.tiles_x[l] = (a.W[l] + a.TW[l] - 1) / a.TW[l];
+        a.tile_off[l] = (int32_t)tiles;
+        tiles += (int64_t)d->batch * a.tiles_y[l] * a.tiles_x[l];
+        if (tiles > 2147483647LL) return IA_E_ARG;
+        for (int g = 0; g < d->groups; ++g) {
+            if (!d->x[g][l] || !d->y[g][l] || ((uintptr_t)d->x[g][l] & 15u) || ((uintptr_t)d->y[g][l] & 3u))
+                return IA_E_ARG;
+            a.x[g][l] = static_cast<const uint16_t *>(d->x[g][l]);
+            a.y[g][l] = static_cast<uint16_t *>(d->y[g][l]);
+        }
+    }
+    for (int l = d->num_levels; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
+    hipLaunchKernelGGL(ia::k_conv3x3_bf16, dim3((unsigned)tiles, (unsigned)(d->groups * a.ntile)), dim3(ia::kCvThreads), 0,
                        (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }

@@ -63,6 +63,14 @@ class WinoGeom(C.Structure):
                 ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS)]
 
 
+class Conv3x3Desc(C.Structure):
+    """ia_conv3x3_desc"""
+    _fields_ = [('num_levels', C.c_int32), ('batch', C.c_int32), ('groups', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32), ('x_stride', C.c_int32), ('y_stride', C.c_int32),
+                ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS),
+                ('x', (C.c_void_p * IA_MAX_LEVELS) * 2), ('y', (C.c_void_p * IA_MAX_LEVELS) * 2)]
+
+
 class WinoSeg(C.Structure):
     _fields_ = [('c0', C.c_int32), ('n', C.c_int32), ('dst_channels', C.c_int32),
                 ('dst_offset', C.c_int32), ('dst', C.c_void_p * IA_MAX_LEVELS)]
@@ -158,9 +166,9 @@ SIGNATURES = {
     'ia_channel_affine_act_nhwc': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'ia_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i64, _vp]),
     'ia_upsample2x_add_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'ia_conv3x3_bf16_packed_bytes': (C.c_size_t, [_i, _i]),
-    'ia_conv3x3_bf16_pack': (_i, [_vp, _i, _i, _vp, _vp]),
-    'ia_conv3x3_bf16_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ia_conv3x3_bf16_packed_bytes': (C.c_size_t, [_i, _i, _i]),
+    'ia_conv3x3_bf16_pack': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'ia_conv3x3_bf16_levels': (_i, [_vp, _vp, _vp, _i, _vp]),
     'ia_upsample2x_add_nhwc_dt': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_affine_relu_maxpool_nhwc_dt': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'ia_affine_relu_maxpool_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -546,30 +546,65 @@ def affine_relu_maxpool(x, scale, shift):
     return out
 
 
-def conv3x3_bf16_pack(weight):
-    """(Cout, Cin, 3, 3) weight -> the packed bf16 layout of `conv3x3_bf16` (once per model)"""
+def conv3x3_bf16_pack(weight, groups=1):
+    """(groups * Cout, Cin, 3, 3) weight -> the packed bf16 layout of `conv3x3_bf16_levels`
+    (once per model); Cin % 32 == 0, Cout even"""
     _require_gpu(weight, 'weight')
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or ci % 32 or co % 256:
-        raise ValueError('conv3x3_bf16 needs a 3x3 kernel, Cin % 32 == 0, Cout % 256 == 0')
+    if (kh, kw) != (3, 3) or ci % 32 or co % groups or (co // groups) % 2 or not 1 <= groups <= 2:
+        raise ValueError('conv3x3_bf16 needs a 3x3 kernel, Cin % 32 == 0, an even Cout per group, groups <= 2')
     w = weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()      # (Cout, 3, 3, Cin)
-    wp = torch.empty(co * 9 * ci, dtype=torch.bfloat16, device=weight.device)
-    _lib.check(_lib.lib().ia_conv3x3_bf16_pack(_ptr(w), ci, co, _ptr(wp), _stream()), 'ia_conv3x3_bf16_pack')
+    nbytes = _lib.lib().ia_conv3x3_bf16_packed_bytes(ci, co // groups, groups)
+    wp = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(_lib.lib().ia_conv3x3_bf16_pack(_ptr(w), ci, co // groups, groups, _ptr(wp), _stream()),
+               'ia_conv3x3_bf16_pack')
     return wp
 
 
+def conv3x3_bf16_levels(xs, wp, bias, cout, ys, relu=False, cin=None):
+    """3x3 / stride 1 / pad 1 convolution + bias (+ReLU) of bf16 channels-last tensors on the MFMA
+    implicit-GEMM kernel (csrc/conv3x3_bf16.hip), all levels and groups in ONE launch.
+    xs / ys: list over groups of lists over levels of (B, C, H, W) channels-last bf16 tensors;
+    a group's tensors may be channel slices [c0, c0 + n) of wider tensors (the cls / reg halves of
+    one activation).  cout / cin: channels per group; wp from conv3x3_bf16_pack; bias fp32
+    (groups * cout) or None.  Writes ys in place and returns them."""
+    groups, L = len(xs), len(xs[0])
+    x0, y0 = xs[0][0], ys[0][0]
+    _require_gpu(x0, 'x')
+    cin = int(cin if cin is not None else x0.shape[1])
+    d = _lib.Conv3x3Desc()
+    d.num_levels, d.batch, d.groups = L, int(x0.shape[0]), groups
+    d.cin, d.cout = cin, int(cout)
+
+    def pix_stride(t):
+        # channels-last (possibly a channel slice): stride of W = channels of the underlying tensor
+        if t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(1) != 1:
+            raise TypeError('conv3x3_bf16_levels needs channels-last bf16 tensors')
+        st = t.stride(3) if t.shape[3] > 1 else (t.stride(2) if t.shape[2] > 1 else t.shape[1])
+        if (t.shape[2] > 1 and t.shape[3] > 1 and t.stride(2) != t.shape[3] * st) or \
+                (t.shape[0] > 1 and t.stride(0) != t.shape[2] * t.shape[3] * st):
+            raise TypeError('conv3x3_bf16_levels: tensor is not a dense channels-last (slice)')
+        return int(st)
+    d.x_stride, d.y_stride = pix_stride(x0), pix_stride(y0)
+    for l in range(L):
+        d.H[l], d.W[l] = int(xs[0][l].shape[2]), int(xs[0][l].shape[3])
+        for g in range(groups):
+            x, y = xs[g][l], ys[g][l]
+            if x.shape[1] != cin or y.shape[1] != cout or x.shape[2:] != y.shape[2:] or x.shape[0] != d.batch \
+                    or tuple(x.shape[2:]) != (d.H[l], d.W[l]) or pix_stride(x) != d.x_stride \
+                    or pix_stride(y) != d.y_stride:
+                raise ValueError('conv3x3_bf16_levels: inconsistent tensors at group %d level %d' % (g, l))
+            d.x[g][l], d.y[g][l] = x.data_ptr(), y.data_ptr()
+    _lib.check(_lib.lib().ia_conv3x3_bf16_levels(C.byref(d), _ptr(wp), _ptr(bias), int(bool(relu)), _stream()),
+               'ia_conv3x3_bf16_levels')
+    return ys
+
+
 def conv3x3_bf16(x, wp, bias, cout, relu=False):
-    """3x3 / stride 1 / pad 1 convolution + bias (+ReLU) of a channels-last bf16 tensor on the
-    MFMA implicit-GEMM kernel (csrc/conv3x3_bf16.hip); wp from conv3x3_bf16_pack, bias fp32"""
-    _require_gpu(x, 'x')
-    B, ci, H, W = x.shape
-    if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
-        raise TypeError('conv3x3_bf16 needs a channels-last bf16 tensor')
-    if wp.numel() != cout * 9 * ci:
-        raise ValueError('packed weight does not match (Cin, Cout)')
-    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    _lib.check(_lib.lib().ia_conv3x3_bf16_nhwc(_ptr(x), _ptr(wp), _ptr(bias), int(bool(relu)), B, H, W, ci, cout,
-                                               _ptr(y), _stream()), 'ia_conv3x3_bf16_nhwc')
+    """one tensor, one group: see conv3x3_bf16_levels"""
+    y = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    conv3x3_bf16_levels([[x]], wp, bias, cout, [[y]], relu=relu)
     return y
 
 

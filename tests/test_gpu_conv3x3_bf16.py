@@ -38,3 +38,38 @@ def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias):
     e_eager = float((eager.double() - want).pow(2).mean().sqrt())
     e_mine = float((y.double() - want).pow(2).mean().sqrt())
     assert e_mine <= 1.2 * e_eager + 1e-6, (e_mine, e_eager)
+
+
+def test_conv3x3_bf16_levels_groups_slices_and_odd_widths():
+    """one launch over five pyramid levels and two groups whose tensors are channel halves of
+    512-channel activations (the cls / reg towers), and a 720-channel output (three column tiles,
+    the last one partial) -- against fp64 convolutions of the bf16-rounded inputs"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(11)
+    sizes = [(28, 40), (14, 20), (7, 10), (4, 5), (2, 3)]
+    B, F = 2, 256
+    cl = torch.channels_last
+    acts = [torch.randn(B, 2 * F, h, w, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
+            for h, w in sizes]
+    outs = [torch.zeros_like(a) for a in acts]
+    w2 = (torch.randn(2 * F, F, 3, 3, device='cuda', generator=g) * 0.03).to(torch.bfloat16)
+    b2 = torch.randn(2 * F, device='cuda', generator=g)
+    wp = ops.conv3x3_bf16_pack(w2, groups=2)
+    ops.conv3x3_bf16_levels([[a[:, :F] for a in acts], [a[:, F:] for a in acts]], wp, b2, F,
+                            [[o[:, :F] for o in outs], [o[:, F:] for o in outs]], relu=True)
+    for a, o in zip(acts, outs):
+        for k in range(2):
+            want = torch.nn.functional.conv2d(a[:, k * F:(k + 1) * F].double(), w2[k * F:(k + 1) * F].double(),
+                                              b2[k * F:(k + 1) * F].double(), 1, 1).clamp(min=0)
+            err = (o[:, k * F:(k + 1) * F].double() - want).abs()
+            assert bool((err <= 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())).all()), float(err.max())
+    # 720 output channels from the cls half of the activations
+    wc = (torch.randn(720, F, 3, 3, device='cuda', generator=g) * 0.03).to(torch.bfloat16)
+    bc = torch.randn(720, device='cuda', generator=g)
+    wpc = ops.conv3x3_bf16_pack(wc)
+    cls = [torch.full((B, 720, h, w), 7.0, device='cuda').to(torch.bfloat16).contiguous(memory_format=cl) for h, w in sizes]
+    ops.conv3x3_bf16_levels([[a[:, :F] for a in acts]], wpc, bc, 720, [cls], relu=False)
+    for a, o in zip(acts, cls):
+        want = torch.nn.functional.conv2d(a[:, :F].double(), wc.double(), bc.double(), 1, 1)
+        err = (o.double() - want).abs()
+        assert bool((err <= 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())).all()), float(err.max())
