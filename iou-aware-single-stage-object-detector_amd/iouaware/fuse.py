@@ -282,9 +282,29 @@ def _head_forward(self, feats):
             _fold(self)
             w = self._ia_wino
         return w(list(feats))
+    if (not self.training) and _bf16_head_ok(feats):
+        # bf16 (BASELINE config 3): towers + class output on the MFMA implicit-GEMM kernel
+        if getattr(self, '_ia_dirty', False) or self._ia_stamp != _stamp(self):
+            _fold(self)
+        c3 = getattr(self, '_ia_c3', None)
+        if c3 is None:
+            from .conv3x3_bf16 import Bf16ConvHead
+            try:
+                c3 = Bf16ConvHead(self)
+            except NotImplementedError:
+                c3 = False
+            self._ia_c3 = c3
+        if c3 and c3.usable(feats):
+            return c3(feats)
     if self.training or torch.is_grad_enabled():
         _mark_dirty(self)              # see _fast: fused optimizers do not bump version counters
     return type(self).forward(self, feats)
+
+
+def _bf16_head_ok(feats):
+    return (not torch.is_grad_enabled()) and all(
+        x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+        and x.is_contiguous(memory_format=torch.channels_last) for x in feats)
 
 
 def _wino_ok(conv):
@@ -311,6 +331,7 @@ def _fold(m):
     if type(m).__name__ == 'IoUawareRetinaHead':
         from .winograd import WinogradHead
         m._ia_wino = WinogradHead(m)
+        m._ia_c3 = None                           # bf16 weights are packed on the first bf16 call
     elif isinstance(m, Bottleneck):
         f = {}
         f['s1'], f['b1'] = _fold_bn(m.norm1)
@@ -458,7 +479,7 @@ def refresh_fused(model):
 
 def unfuse_inference(model):
     for m in model.modules():
-        for attr in ('_ia_fused', '_ia_wino', '_ia_opts', '_ia_stamp', '_ia_dirty'):
+        for attr in ('_ia_fused', '_ia_wino', '_ia_c3', '_ia_opts', '_ia_stamp', '_ia_dirty'):
             if hasattr(m, attr):
                 delattr(m, attr)
                 for name in ('forward', '_stem', '_stages'):
