@@ -30,7 +30,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int kCvThreads = 512;
 constexpr int kCvBK = 32;                 // input channels per K step
 constexpr int kCvRow = 80;                // bytes per LDS row (64 of data)
-constexpr int kCvMaxPatch = 352;          // (TH + 2) * (TW + 2) <= this
+constexpr int kCvMaxPatch = 352;          // (TH + 2) * (TW + 2) <= this (256-pixel tiles)
+constexpr int kCvMaxPatchHalf = 208;      // ... for 128-pixel tiles
 constexpr int kCvBN = 256;
 
 constexpr int kCvMaxGroups = 2;
@@ -54,9 +55,14 @@ __device__ __forceinline__ uint32_t bf16_rne(float f)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// MB = 32-pixel accumulator blocks per wavefront: 4 (256-pixel tiles) or 2 (128-pixel tiles, for
+// feature maps whose 256-pixel tiles would leave most of the chip's workgroup slots empty)
+template <int MB>
 __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_a[kCvMaxPatch * kCvRow];
+    constexpr int kPatch = MB == 4 ? kCvMaxPatch : kCvMaxPatchHalf;
+    constexpr int kWM = 32 * MB;                           // pixels per wavefront
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[kPatch * kCvRow];
     __shared__ __attribute__((aligned(16))) unsigned char s_b[2][kCvBN * kCvRow];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 2, wn = wv & 3;                  // 2 x 4 wavefronts
@@ -73,10 +79,10 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     const int nchunk = a.Cin / kCvBK, nsteps = nchunk * 9;
 
     // ---- this lane's four A rows (pixels) as byte offsets into the patch (tap (0,0) corner)
-    int a_off[4];
+    int a_off[MB];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        int m = wm * 128 + mb * 32 + (lane & 31);
+    for (int mb = 0; mb < MB; ++mb) {
+        int m = wm * kWM + mb * 32 + (lane & 31);
         m = m < tile_px ? m : tile_px - 1;                // idle rows read a valid address
         const int ty = m / TW, tx = m - ty * TW;
         a_off[mb] = (ty * PW + tx) * kCvRow + (lane >> 5) * 16;
@@ -106,19 +112,19 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
     }
     CV_PIECE(0, pa0, in0, on0)
     CV_PIECE(1, pa1, in1, on1)
-    CV_PIECE(2, pa2, in2, on2)
+    if (MB == 4) CV_PIECE(2, pa2, in2, on2) else { pa2 = pa1; in2 = on2 = false; }
 #undef CV_PIECE
     // (an AND with a per-piece mask: `in ? value : zero` on a 128-bit value became a table in scratch)
     const uint32_t mk0 = in0 ? 0xffffffffu : 0u, mk1 = in1 ? 0xffffffffu : 0u, mk2 = in2 ? 0xffffffffu : 0u;
     unsigned char *sa0 = s_a + (tid >> 2) * kCvRow + (tid & 3) * 16;
     unsigned char *sa1 = sa0 + (kCvThreads >> 2) * kCvRow, *sa2 = sa1 + (kCvThreads >> 2) * kCvRow;
     const int sb_off = (tid >> 2) * kCvRow + (tid & 3) * 16;               // + 128 rows for the second piece
-    uint4 ra0, ra1, ra2, rx0, rx1, ry0, ry1;
+    uint4 ra0, ra1, ra2 = make_uint4(0u, 0u, 0u, 0u), rx0, rx1, ry0, ry1;
 #define CV_LOAD_A(chunk)                                                                            \
     {                                                                                               \
         ra0 = *reinterpret_cast<const uint4 *>(pa0 + (chunk) * kCvBK);                              \
         ra1 = *reinterpret_cast<const uint4 *>(pa1 + (chunk) * kCvBK);                              \
-        ra2 = *reinterpret_cast<const uint4 *>(pa2 + (chunk) * kCvBK);                              \
+        if (MB == 4) ra2 = *reinterpret_cast<const uint4 *>(pa2 + (chunk) * kCvBK);                 \
     }
 #define CV_STORE_A()                                                                                \
     {                                                                                               \
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
            full memory round trip in the middle of the K loop */                                    \
         if (on0) *reinterpret_cast<uint4 *>(sa0) = make_uint4(ra0.x & mk0, ra0.y & mk0, ra0.z & mk0, ra0.w & mk0); \
         if (on1) *reinterpret_cast<uint4 *>(sa1) = make_uint4(ra1.x & mk1, ra1.y & mk1, ra1.z & mk1, ra1.w & mk1); \
-        if (on2) *reinterpret_cast<uint4 *>(sa2) = make_uint4(ra2.x & mk2, ra2.y & mk2, ra2.z & mk2, ra2.w & mk2); \
+        if (MB == 4 && on2) *reinterpret_cast<uint4 *>(sa2) = make_uint4(ra2.x & mk2, ra2.y & mk2, ra2.z & mk2, ra2.w & mk2); \
     }
 #define CV_LOAD_B(step, R0, R1)                                                                     \
     {                                                                                               \
@@ -140,9 +146,9 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
         *reinterpret_cast<uint4 *>(s_b[buf] + sb_off + 128 * kCvRow) = R1;                          \
     }
 
-    f32x16 acc[4][2];
+    f32x16 acc[MB][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -171,12 +177,12 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
         const unsigned char *ab = s_a + (dy * PW + dx) * kCvRow;                                    \
         const unsigned char *bb = s_b[0] + ((step & 1) ? kCvBN * kCvRow : 0) + b_off;               \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
-            bf16x8 fa[4], fb[2];                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+            bf16x8 fa[MB], fb[2];                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MB; ++i)                                          \
                 fa[i] = *reinterpret_cast<const bf16x8 *>(ab + a_off[i] + kk * 32);                 \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
                 fb[j] = *reinterpret_cast<const bf16x8 *>(bb + j * 32 * kCvRow + kk * 32);          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+            _Pragma("unroll") for (int i = 0; i < MB; ++i)                                          \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0); \
         }                                                                                           \
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
         const bool n_ok = (n - odd) + 1 < a.Cout;                             // the pair this lane stores (Cout is even)
         const float bz = (a.bias && n < a.Cout) ? a.bias[grp * a.Cout + n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MB; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float v0 = acc[i][j][r] + bz, v1 = acc[i][j][r + 1] + bz;
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(kCvThreads, 2) k_conv3x3_bf16(Conv3Args a)
                 const float give = odd ? v0 : v1;
                 const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
                 const int rr = odd ? r + 1 : r;
-                const int m = wm * 128 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                const int m = wm * kWM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
                 const uint32_t lo = bf16_rne(odd ? got : v0), hi = bf16_rne(odd ? v1 : got);
                 if (m < tile_px) {
                     const int ty = m / TW, tx = m - ty * TW;
@@ -261,17 +267,16 @@ __global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_
     wp[idx] = co < Cout ? w[(((size_t)(g * Cout + co) * 9) + tap) * Cin + chunk * kCvBK + k] : (uint16_t)0;
 }
 
-// tile shape for an H x W map: TH * TW <= 256, patch <= kCvMaxPatch, least overhang
-static void conv3_tile_shape(int H, int W, int &TH, int &TW)
+// tile shape for an H x W map: TH * TW <= max_px, patch <= max_patch, least overhang
+static void conv3_tile_shape(int H, int W, int max_px, int max_patch, int &TH, int &TW)
 {
     double best = -1.0;
-    TH = 16; TW = 16;
+    TH = 8; TW = 16;
     for (int tw = 4; tw <= 64; ++tw) {
         for (int th = 2; th <= 64; ++th) {
-            if (th * tw > 256 || (th + 2) * (tw + 2) > kCvMaxPatch) continue;
+            if (th * tw > max_px || (th + 2) * (tw + 2) > max_patch) continue;
             const int64_t ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
-            // useful pixels per 256-row tile
-            const double eff = (double)H * W / ((double)ty * tx * 256.0);
+            const double eff = (double)H * W / ((double)ty * tx * max_px);      // useful rows per tile
             if (eff > best + 1e-9) { best = eff; TH = th; TW = tw; }
         }
     }
@@ -309,15 +314,9 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
     a.L = d->num_levels; a.B = d->batch; a.Cin = d->cin; a.Cout = d->cout; a.xs = d->x_stride; a.ys = d->y_stride;
     a.relu = relu ? 1 : 0; a.ntile = (d->cout + ia::kCvBN - 1) / ia::kCvBN;
-    int64_t tiles = 0;
     for (int l = 0; l < d->num_levels; ++l) {
         if (d->H[l] < 1 || d->W[l] < 1) return IA_E_ARG;
         a.H[l] = d->H[l]; a.W[l] = d->W[l];
-        ia::conv3_tile_shape(a.H[l], a.W[l], a.TH[l], a.TW[l]);
-        a.tiles_y[l] = (a.H[l] + a.TH[l] - 1) / a.TH[l]; a.tiles_x[l] = (a.W[l] + a.TW[l] - 1) / a.TW[l];
-        a.tile_off[l] = (int32_t)tiles;
-        tiles += (int64_t)d->batch * a.tiles_y[l] * a.tiles_x[l];
-        if (tiles > 2147483647LL) return IA_E_ARG;
         for (int g = 0; g < d->groups; ++g) {
             if (!d->x[g][l] || !d->y[g][l] || ((uintptr_t)d->x[g][l] & 15u) || ((uintptr_t)d->y[g][l] & 3u))
                 return IA_E_ARG;
@@ -325,9 +324,26 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
             a.y[g][l] = static_cast<uint16_t *>(d->y[g][l]);
         }
     }
+    // 256-pixel tiles unless they fill less than a round and a half of the chip's 512 resident
+    // workgroups: then 128-pixel tiles (twice the workgroups, half the accumulators each)
+    int64_t tiles = 0;
+    int mb = 4;
+    for (int pass = 0; pass < 2; ++pass) {
+        tiles = 0;
+        for (int l = 0; l < d->num_levels; ++l) {
+            ia::conv3_tile_shape(a.H[l], a.W[l], 64 * mb, mb == 4 ? ia::kCvMaxPatch : ia::kCvMaxPatchHalf, a.TH[l], a.TW[l]);
+            a.tiles_y[l] = (a.H[l] + a.TH[l] - 1) / a.TH[l]; a.tiles_x[l] = (a.W[l] + a.TW[l] - 1) / a.TW[l];
+            a.tile_off[l] = (int32_t)tiles;
+            tiles += (int64_t)d->batch * a.tiles_y[l] * a.tiles_x[l];
+            if (tiles > 2147483647LL) return IA_E_ARG;
+        }
+        if (mb == 2 || tiles * d->groups * a.ntile >= 768) break;
+        mb = 2;
+    }
     for (int l = d->num_levels; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
-    hipLaunchKernelGGL(ia::k_conv3x3_bf16, dim3((unsigned)tiles, (unsigned)(d->groups * a.ntile)), dim3(ia::kCvThreads), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
+    if (mb == 4) hipLaunchKernelGGL(ia::k_conv3x3_bf16<4>, grid, dim3(ia::kCvThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ia::k_conv3x3_bf16<2>, grid, dim3(ia::kCvThreads), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 
