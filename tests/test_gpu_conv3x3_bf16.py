@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
     (2, 50, 84, 256, 256, True, True),        # P4: 9 x 28 tiles
     (1, 100, 168, 256, 256, False, True),     # P3: 10 x 24 tiles
     (1, 33, 17, 96, 512, True, True),         # two column blocks, Cin not a power of two
+    (8, 100, 168, 64, 512, True, True),       # 1 120 workgroups: the 256-pixel-tile kernel (smaller grids take 128-pixel tiles)
 ])
 def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias):
     from iouaware import ops
