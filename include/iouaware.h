@@ -567,6 +567,12 @@ int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W
 int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, int H, int W, int Hc,
                               int Wc, int C, void *stream);
 
+/* 1x1 convolutions of ResNet stage 1 (resnet.py:215-255, folded BatchNorm) as a streaming MFMA
+ * kernel with the weights resident in LDS (csrc/conv1x1_stream.hip): y = relu?(x . w + bias
+ * (+ residual)), fp32, x (rows, k), w (k, n) row-major, (k, n) in {(64, 256), (256, 64), (64, 64)}. */
+int ia_conv1x1_stream(const float *x, const float *w, const float *bias, const float *residual,
+                      float *y, int64_t rows, int k, int n, int relu, void *stream);
+
 /* ------------------------------------------------------------------ bf16 3x3 convolution
  * 3x3 / stride 1 / pad 1 convolution + bias (+ReLU) on bf16 channels-last tensors, fp32
  * accumulation: the tower / output / FPN ConvModules of BASELINE config 3 (reference

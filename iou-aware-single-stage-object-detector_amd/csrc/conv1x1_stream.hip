@@ -1,0 +1,122 @@
+// 1x1 convolutions of ResNet stage 1 as streaming MFMA kernels (fp32): y = relu?(x . W + bias
+// (+ residual)) for K x N = 64 x 256, 256 x 64, 64 x 64 (reference mmdet/models/backbones/
+// resnet.py:215-255, the bottleneck's conv1 / conv3 with the folded BatchNorm).  These products
+// have 7 % of the network's multiply-adds and are HBM-bound (a 64 -> 256 convolution with its
+// residual moves 1.24 GB for 17.6 GFLOP); the library GEMM runs them at 3.8-4.0 TB/s.
+//
+// The whole weight matrix (K * N <= 16 384 floats = 64 KB) sits in LDS; a wavefront streams
+// 16-pixel tiles with NO barrier after the weights are in: it computes D^T = W^T (N x K) . X^T on
+// v_mfma_f32_16x16x4_f32, so that a lane ends up with FOUR CONSECUTIVE OUTPUT CHANNELS of one
+// pixel -- residual loads, the accumulator initialisation and the stores are 16 bytes per lane,
+// 64 contiguous bytes per pixel.  The activation rows are read with 16-byte loads as well: K is a
+// reduction index, so WHICH k a lane group feeds into MFMA step s is free as long as the weight
+// fragment uses the same one: lane (pixel p, group q) loads x[p][16 j + 4 q .. + 3] and step
+// s = 4 j + c consumes k = 16 j + 4 q + c on both operands.
+// All loads of a tile (activation + residual, 20 x 16 bytes per lane for 64 -> 256) are issued
+// before the first MFMA; the residual lands directly in the accumulators.
+#include <string.h>
+#include "ia_internal.hpp"
+
+namespace ia {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct Conv1Args {
+    const float *x, *w, *bias, *res;      // x (P, K), w (K, N), bias (N) or NULL, res (P, N) or NULL
+    float *y;                             // (P, N)
+    int64_t P;
+    int32_t relu, tiles;
+};
+
+constexpr int kC1Threads = 512;
+
+template <int K, int N>
+__global__ void __launch_bounds__(kC1Threads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_conv1x1_stream(Conv1Args a)
+{
+    constexpr int NB = N / 16, J = K / 16, LDW = N + 4;   // + 4 floats: the four k-groups of a read hit different banks
+    __shared__ __attribute__((aligned(16))) float s_w[K * LDW];
+    __shared__ __attribute__((aligned(16))) float s_bias[N];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < K * (N / 4); i += kC1Threads) {
+        const int k = i / (N / 4), n4 = i - k * (N / 4);
+        *reinterpret_cast<float4 *>(s_w + k * LDW + 4 * n4) = *reinterpret_cast<const float4 *>(a.w + (size_t)k * N + 4 * n4);
+    }
+    for (int i = tid; i < N; i += kC1Threads) s_bias[i] = a.bias ? a.bias[i] : 0.0f;
+    __syncthreads();
+
+    const int p_in = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * (kC1Threads / 64) + (tid >> 6), nwaves = gridDim.x * (kC1Threads / 64);
+    // weight fragment of (step s = 4 j + c, block nb): s_w[(16 j + 4 q + c) * LDW + nb * 16 + p_in]
+    const float *wq = s_w + (4 * q) * LDW + p_in;
+    for (int tile = wave; tile < a.tiles; tile += nwaves) {
+        const int64_t p0 = (int64_t)tile * 16 + p_in;
+        const int64_t p = p0 < a.P ? p0 : a.P - 1;         // clamped: loads unconditional
+        const float *xr = a.x + p * K + 4 * q;
+        f32x4 xv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4 *>(xr + 16 * j);
+        f32x4 acc[NB];
+        if (a.res) {
+            const float *rr = a.res + p * N + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rr + 16 * nb));
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 bz = *reinterpret_cast<const f32x4 *>(s_bias + 16 * nb + 4 * q);
+            acc[nb] += bz;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xb = xv[j][c];
+                const float *wrow = wq + (16 * j + c) * LDW;
+                float wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = wrow[16 * nb];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[nb], 0, 0, 0);
+                // the fragment reads of a later step must not climb above this point: fully
+                // unrolled, the scheduler hoisted all K * N / 64 of them and spilled
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (p0 < a.P) {
+            float *yr = a.y + p * N + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 v = acc[nb];
+                if (a.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                *reinterpret_cast<f32x4 *>(yr + 16 * nb) = v;
+            }
+        }
+    }
+}
+
+}  // namespace ia
+
+extern "C" int ia_conv1x1_stream(const float *x, const float *w, const float *bias, const float *residual,
+                                 float *y, int64_t rows, int k, int n, int relu, void *stream)
+{
+    if (!x || !w || !y || rows < 1) return IA_E_ARG;
+    if (((uintptr_t)x & 15u) || ((uintptr_t)w & 15u) || ((uintptr_t)y & 15u) || ((uintptr_t)residual & 15u)) return IA_E_ARG;
+    ia::Conv1Args a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y; a.P = rows; a.relu = relu ? 1 : 0;
+    const int64_t tiles = (rows + 15) / 16;
+    if (tiles > 2147483647LL) return IA_E_ARG;
+    a.tiles = (int32_t)tiles;
+    int64_t wgs = (tiles + 3) / 4;
+    wgs = (tiles + 7) / 8;
+    if (wgs > 512) wgs = 512;                              // two resident workgroups per CU, tiles strided over the wavefronts
+    const dim3 grid((unsigned)wgs), block(ia::kC1Threads);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 64 && n == 256) hipLaunchKernelGGL((ia::k_conv1x1_stream<64, 256>), grid, block, 0, s, a);
+    else if (k == 256 && n == 64) hipLaunchKernelGGL((ia::k_conv1x1_stream<256, 64>), grid, block, 0, s, a);
+    else if (k == 64 && n == 64) hipLaunchKernelGGL((ia::k_conv1x1_stream<64, 64>), grid, block, 0, s, a);
+    else return IA_E_ARG;
+    return ia::hip_status(hipGetLastError());
+}

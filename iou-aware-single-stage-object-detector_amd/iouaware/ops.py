@@ -635,6 +635,14 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
         raise ValueError('residual must be a channels-last tensor of the output shape')
     if residual is not None and residual.dtype != x.dtype:
         raise TypeError('residual dtype mismatch')
+    if x.dtype == torch.float32 and not w_nk and STREAM_1X1 and (k, n) in _STREAM_SHAPES \
+            and B * H * W >= 65536:
+        # ResNet stage 1: HBM-bound products with 16 K weights -> the streaming kernel with the
+        # weights in LDS (csrc/conv1x1_stream.hip; 4.3-4.8 TB/s against the library GEMM's 3.3-3.8)
+        _lib.check(_lib.lib().ia_conv1x1_stream(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out),
+                                                B * H * W, k, n, int(bool(relu)), _stream()),
+                   'ia_conv1x1_stream')
+        return out
     ws = _workspace(x.device, _LT_WS_BYTES)
     if x.dtype == torch.bfloat16:
         if w_nk:
@@ -647,6 +655,28 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
     fn = _lib.lib().ia_linear_bias_act_wt if w_nk else _lib.lib().ia_linear_bias_act
     _lib.check(fn(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out), B * H * W, k, n,
                   int(bool(relu)), _ptr(ws), _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')
+    return out
+
+
+_STREAM_SHAPES = ((64, 256), (256, 64), (64, 64))
+STREAM_1X1 = True                      # linear_bias_act routes these shapes to conv1x1_stream
+
+
+def conv1x1_stream(x, w_kn, bias=None, residual=None, relu=False):
+    """the stage-1 1x1 convolutions on the streaming MFMA kernel (weights in LDS): fp32
+    channels-last, (k, n) in _STREAM_SHAPES; same contract as linear_bias_act"""
+    _require_gpu(x, 'x')
+    B, k, H, W = x.shape
+    n = int(w_kn.shape[1])
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) \
+            or (k, n) not in _STREAM_SHAPES or tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous():
+        raise TypeError('conv1x1_stream: fp32 channels-last input, (k, n) in %s' % (_STREAM_SHAPES,))
+    out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or residual.dtype != torch.float32
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('residual must be a channels-last fp32 tensor of the output shape')
+    _lib.check(_lib.lib().ia_conv1x1_stream(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out),
+                                            B * H * W, k, n, int(bool(relu)), _stream()), 'ia_conv1x1_stream')
     return out
 
 

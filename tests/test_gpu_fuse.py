@@ -189,3 +189,35 @@ def test_fused_bf16_network_matches_unfused():
         for u, v in zip(a, b):
             assert v.dtype == torch.bfloat16
             assert float((u.float() - v.float()).abs().max()) <= 0.08 * float(u.float().abs().max())
+
+
+@pytest.mark.parametrize('k,n,res', [(64, 256, True), (64, 256, False), (256, 64, False), (64, 64, False)])
+def test_conv1x1_stream_matches_fp64(k, n, res):
+    """the streaming stage-1 1x1 kernel (weights in LDS, D^T = W^T X^T on v_mfma_f32_16x16x4_f32)
+    against an fp64 product; partial last tile (rows % 16 != 0); and linear_bias_act routes the
+    large stage-1 shapes to it"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(k + n)
+    x = torch.randn(3, k, 37, 53, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(k, n, device='cuda', generator=g) * 0.1
+    b = torch.randn(n, device='cuda', generator=g)
+    r = torch.randn(3, n, 37, 53, device='cuda', generator=g).contiguous(memory_format=torch.channels_last) if res else None
+    want = torch.einsum('bkhw,kn->bnhw', x.double(), w.double()) + b.double().view(1, -1, 1, 1)
+    if res:
+        want = want + r.double()
+    for relu in (False, True):
+        ref = want.clamp(min=0) if relu else want
+        got = ops.conv1x1_stream(x, w, b, residual=r, relu=relu)
+        assert got.is_contiguous(memory_format=torch.channels_last)
+        assert float((got.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    got = ops.conv1x1_stream(x, w, None, relu=False)
+    assert float((got.double() - (want - b.double().view(1, -1, 1, 1) - (r.double() if res else 0))).abs().max()) \
+        < 1e-5 * float(want.abs().max())
+    big = torch.randn(2, k, 200, 168, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    a = ops.linear_bias_act(big, w, b, relu=True)                   # routed to the streaming kernel
+    ops.STREAM_1X1 = False
+    try:
+        lib = ops.linear_bias_act(big, w, b, relu=True)
+    finally:
+        ops.STREAM_1X1 = True
+    assert float((a - lib).abs().max()) < 1e-5 * float(lib.abs().max())

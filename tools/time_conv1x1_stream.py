@@ -1,0 +1,30 @@
+"""ResNet stage-1 1x1 convolutions (batch 8, 200x336): the streaming MFMA kernel with the weights in
+LDS (csrc/conv1x1_stream.hip) against the library GEMM with the fused epilogue (ops.linear_bias_act)."""
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(ROOT, 'iou-aware-single-stage-object-detector_amd'))
+import torch
+from iouaware import ops
+ops.gemm_tuning('all')
+B, H, W = 8, 200, 336
+def bench(fn, n=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+cl = torch.channels_last
+for k, n, res in ((64, 256, True), (256, 64, False), (64, 64, False), (64, 256, False)):
+    x = torch.randn(B, k, H, W, device='cuda').contiguous(memory_format=cl)
+    w = torch.randn(k, n, device='cuda') * 0.05
+    b = torch.randn(n, device='cuda')
+    r = torch.randn(B, n, H, W, device='cuda').contiguous(memory_format=cl) if res else None
+    want = ops.linear_bias_act(x, w, b, residual=r, relu=True)
+    got = ops.conv1x1_stream(x, w, b, residual=r, relu=True)
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    mb = (x.numel() + (r.numel() if res else 0) + want.numel()) * 4 / 1e6
+    t0 = bench(lambda: ops.linear_bias_act(x, w, b, residual=r, relu=True))
+    t1 = bench(lambda: ops.conv1x1_stream(x, w, b, residual=r, relu=True))
+    print('%3d -> %3d res=%d  %.0f MB  library %.1f us (%.2f TB/s)   own %.1f us (%.2f TB/s)   max rel diff %.1e'
+          % (k, n, res, mb, t0 * 1e3, mb / t0 / 1e3, t1 * 1e3, mb / t1 / 1e3, err), flush=True)
