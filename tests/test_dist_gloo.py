@@ -220,6 +220,14 @@ def _run_bench(argv, env_extra=None):
     return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()
 
 
+def test_bench_gpus_8_dry_run():
+    """the node size the driver's scaling run uses: eight ranks, rank interleave of the gathered
+    records over 8 shards"""
+    rc, rec, err = _run_bench(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1'])
+    assert rc == 0, err[-2000:]
+    assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['exchange_ok'] is True
+
+
 def test_bench_gpus_flag_starts_the_ranks_itself():
     """`python bench.py --gpus 2` (no launcher) must start 2 ranks -- the
     reference's launcher takes the GPU count and spawns (tools/dist_test.sh:7-10).  --dry-run:
