@@ -194,59 +194,157 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(model, stepper):
-    """Same workload on the host cores, bounded sample: ONE image of the batch, twice:
-    convs on all torch threads, then on one thread; the post-conv path is the C oracle (1 thread:
-    the reference's NMS is serial by construction), a port of the reference CPU path pinned
-    against it by tests/golden."""
+def _numa_cores():
+    """physical cores (one hardware thread each) of NUMA node 0 and of the whole host, restricted
+    to this process's affinity mask: [[cpu ids of node 0], [cpu ids of all nodes]]"""
+    allowed = os.sched_getaffinity(0)
+
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(','):
+            if '-' in part:
+                lo, hi = part.split('-')
+                out += list(range(int(lo), int(hi) + 1))
+            elif part:
+                out.append(int(part))
+        return out
+
+    def first_threads(cpus):
+        seen, out = set(), []
+        for c in sorted(cpus):
+            try:
+                with open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c) as f:
+                    sib = tuple(sorted(parse(f.read())))
+            except OSError:
+                sib = (c,)
+            if sib not in seen:
+                seen.add(sib)
+                out.append(c)
+        return out
+    try:
+        with open('/sys/devices/system/node/node0/cpulist') as f:
+            node0 = [c for c in parse(f.read()) if c in allowed]
+    except OSError:
+        node0 = sorted(allowed)
+    return first_threads(node0 or sorted(allowed)), first_threads(sorted(allowed))
+
+
+def cpu_worker(spec):
+    """--cpu-worker: one point of the CPU sweep in its own process, so that the OpenMP runtime
+    starts with the binding of THIS point (OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES are read
+    once, at its initialisation).  Convolutions: PyTorch-CPU (oneDNN) on the plain modules, random
+    init seed 0 like the GPU model; post-conv path: the C oracle, one image per thread."""
+    spec = json.loads(spec)
+    threads, batch = int(spec['threads']), int(spec['batch'])
+    if spec.get('cpus'):
+        os.sched_setaffinity(0, set(spec['cpus']))
+    torch.set_num_threads(threads)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import copy
     import oracle
     oracle.build()
-    cpu_model = copy.deepcopy(model).to('cpu').eval()   # fused forwards fall back on CPU tensors
-    img = stepper.imgs[:1].cpu()
-    threads0 = torch.get_num_threads()
-    # the cores this process may run on (a container's cpuset can be far smaller than the host)
-    threads = max(1, min(threads0, len(os.sched_getaffinity(0))))
-    torch.set_num_threads(threads)
+    model = build_model(torch.device('cpu'), fuse=False)
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(batch, 3, PAD_H, PAD_W, generator=g)
+    if spec.get('channels_last'):
+        model = model.to(memory_format=torch.channels_last)
+        img = img.contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        # one untimed pass at full size: oneDNN creates its primitives / reorders the weights at
-        # the first call of every shape, which is not steady-state throughput
-        cpu_model.forward_head(img)
+        # one untimed pass: oneDNN creates its primitives / reorders the weights at the first call
+        # of every shape, which is not steady-state throughput
+        model.forward_head(img)
         t0 = time.time()
-        cls, reg, iou = cpu_model.forward_head(img)
+        cls, reg, iou = model.forward_head(img)
         t_conv = time.time() - t0
-    head = cpu_model.bbox_head
-    base = np.stack([g.base_anchors.numpy() for g in head.anchor_generators])
+    head = model.bbox_head
+    base = np.stack([a.base_anchors.numpy() for a in head.anchor_generators])
+    cls, reg, iou = ([t.contiguous().numpy() for t in x] for x in (cls, reg, iou))
+
+    def post(b):
+        return oracle.get_bboxes_single([c[b] for c in cls], [r[b] for r in reg], [i[b] for i in iou],
+                                        head.anchor_strides, base, (IMG_H, IMG_W), 1.0, True,
+                                        TEST_CFG['nms_pre'], TEST_CFG['score_thr'],
+                                        TEST_CFG['nms']['iou_thr'], TEST_CFG['max_per_img'])
     t0 = time.time()
-    res = oracle.get_bboxes_single([c[0].numpy() for c in cls], [r[0].numpy() for r in reg],
-                                   [i[0].numpy() for i in iou], head.anchor_strides, base,
-                                   (IMG_H, IMG_W), 1.0, True, TEST_CFG['nms_pre'],
-                                   TEST_CFG['score_thr'], TEST_CFG['nms']['iou_thr'],
-                                   TEST_CFG['max_per_img'])
+    if batch == 1:
+        res = [post(0)]
+    else:
+        # the reference's NMS is serial per image; images are independent -> one per thread
+        # (ctypes drops the GIL inside the C call)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(batch, threads)) as ex:
+            res = list(ex.map(post, range(batch)))
     t_post = time.time() - t0
-    torch.set_num_threads(1)
-    try:
-        with torch.no_grad():
-            t0 = time.time()
-            cpu_model.forward_head(img)
-            t_conv1 = time.time() - t0
-    finally:
-        torch.set_num_threads(threads0)
-    total = t_conv + t_post
-    into_nms = int((res['mlvl_scores'] > TEST_CFG['score_thr']).sum())
+    print(json.dumps(dict(threads=threads, batch=batch, conv_s=round(t_conv, 3), post_s=round(t_post, 3),
+                          img_per_s=round(batch / (t_conv + t_post), 4),
+                          into_nms=int((res[0]['mlvl_scores'] > TEST_CFG['score_thr']).sum()),
+                          dets=int(res[0]['num_det']))))
+
+
+def cpu_baseline(model=None, stepper=None, budget_s=150.0):
+    """The same workload on the host cores: a thread SWEEP, each point in its own
+    process bound to the first n physical cores of NUMA node 0 (OMP_PROC_BIND=close,
+    OMP_PLACES=cores, affinity mask), one warm-up pass, one timed pass:
+      latency-configured    ONE image at a time (the reference asserts batch 1 at test time,
+                            base.py:96-98) on 1 / 8 / 16 / 32 / 64 / all cores of the socket;
+                            `value` = the best point, the table is reported;
+      throughput-configured batch 8 in one forward on the socket's cores (and on all sockets), the
+                            eight post-conv problems on eight threads.
+    Convolutions: PyTorch-CPU; post-conv path: the C oracle (oracle/, a port of the reference CPU
+    path pinned against it by tests/golden; serial per image by construction)."""
+    node0, allc = _numa_cores()
+    t_start = time.time()
+
+    def run(threads, batch, cpus, timeout):
+        env = dict(os.environ)
+        env.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND='close',
+                   OMP_PLACES='cores', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+        spec = json.dumps(dict(threads=threads, batch=batch, cpus=cpus))
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', spec], env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            return json.loads(out.stdout.decode().strip().splitlines()[-1])
+        except Exception as exc:
+            return dict(threads=threads, batch=batch, error='%s: %s' % (type(exc).__name__, str(exc)[:200]))
+    points = sorted(set(n for n in (1, 8, 16, 32, 64, len(node0)) if n <= len(node0)))
+    table = []
+    for n in points:
+        if time.time() - t_start > budget_s * 0.6:
+            table.append(dict(threads=n, batch=1, skipped='time budget'))
+            continue
+        table.append(run(n, 1, node0[:n], 120))
+    ok = [r for r in table if 'img_per_s' in r]
+    best = max(ok, key=lambda r: r['img_per_s']) if ok else None
+    one = next((r for r in ok if r['threads'] == 1), None)
+    thr = []
+    for n, cpus, what in ((len(node0), node0, 'one socket (NUMA node 0)'), (len(allc), allc, 'all sockets')):
+        if (what == 'all sockets' and len(allc) == len(node0)) or time.time() - t_start > budget_s:
+            continue
+        r = run(n, BATCH, cpus, 240)
+        r['cores_of'] = what
+        thr.append(r)
+    thr_ok = [r for r in thr if 'img_per_s' in r]
+    tbest = max(thr_ok, key=lambda r: r['img_per_s']) if thr_ok else None
     name = cpu_model_name()
-    return dict(value=round(1.0 / total, 4), unit='img/s', cores=threads, kind='port',
-                cpu=name, host_cores=os.cpu_count(),
-                configuration='latency-configured: ONE image at a time (the reference asserts batch 1 at '
-                              'test time, base.py:96-98); oneDNN convolutions at batch 1 scale poorly over '
-                              'the cores, the NMS is serial by construction -- not a throughput-tuned CPU run',
-                sample='1 image of the batch (3x800x1344): PyTorch-CPU convs %.2f s on %d threads'
-                       ' + C oracle get_bboxes %.2f s on 1 thread (%d boxes into NMS); host: %s,'
-                       ' %d cores' % (t_conv, threads, t_post, into_nms, name, os.cpu_count()),
-                single_thread=dict(value=round(1.0 / (t_conv1 + t_post), 4), unit='img/s', cores=1,
-                                   sample='the same image: PyTorch-CPU convs %.2f s on 1 thread + '
-                                          'C oracle %.2f s' % (t_conv1, t_post)))
+    return dict(value=best['img_per_s'] if best else None, unit='img/s',
+                cores=best['threads'] if best else None, kind='port', cpu=name, host_cores=os.cpu_count(),
+                physical_cores_node0=len(node0), physical_cores_host=len(allc),
+                configuration='latency-configured: ONE image at a time (the reference asserts batch 1 at test '
+                              'time, base.py:96-98); best point of a thread sweep, every point in its own process '
+                              'bound to the first n physical cores of NUMA node 0 (OMP_PROC_BIND=close, '
+                              'OMP_PLACES=cores), one warm-up pass then one timed pass',
+                sample='1 image (3x800x1344, random-init R-50): PyTorch-CPU convs %.2f s on %d threads + C oracle '
+                       'get_bboxes %.2f s on 1 thread (%d boxes into NMS); host: %s, %d hardware threads'
+                       % (best['conv_s'], best['threads'], best['post_s'], best['into_nms'], name,
+                          os.cpu_count()) if best else 'no point of the sweep finished',
+                sweep=table,
+                single_thread=dict(value=one['img_per_s'], unit='img/s', cores=1,
+                                   sample='convs %.2f s + C oracle %.2f s' % (one['conv_s'], one['post_s']))
+                if one else None,
+                throughput=dict(value=tbest['img_per_s'], unit='img/s', cores=tbest['threads'], batch=BATCH,
+                                configuration='throughput-configured: batch 8 in one forward, the 8 post-conv '
+                                              'problems on 8 threads (serial per image by construction)',
+                                runs=thr) if tbest else dict(value=None, runs=thr),
+                seconds=round(time.time() - t_start, 1))
 
 
 TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4,
@@ -630,10 +728,18 @@ def main():
                     help='r50 = BASELINE config 2 (the headline); r101-bf16 = config 3; '
                          'x101-64x4d = config 4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='print the cpu_baseline record alone (no GPU needed)')
     ap.add_argument('--no-train', action='store_true', help='skip the training sub-record')
     ap.add_argument('--no-pipeline', action='store_true', help='skip the image -> result sub-record')
     ap.add_argument('--train-find', action='store_true',
                     help='MIOpen find mode for the training sub-record (adds ~8 minutes)')
+    ap.add_argument('--miopen-find', action='store_true',
+                    help='MIOpen find mode (times the convolution algorithms per process: not '
+                         'reproducible run to run; default: immediate mode)')
+    ap.add_argument('--gemm-tune', default='frozen', choices=['frozen', 'heuristic', 'all'],
+                    help="'frozen' (default): committed tuning table, nothing timed at run time")
     ap.add_argument('--no-fuse', action='store_true', help='keep the eager BN/ReLU/add kernels')
     ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
     ap.add_argument('--no-winograd', action='store_true',
@@ -642,6 +748,11 @@ def main():
                     help='no GPU: fake detections on CPU, gloo backend -- launcher, process group, '
                          'timed region and result exchange only')
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
 
     launched = 'WORLD_SIZE' in os.environ
     launched_by = os.environ.get('IA_BENCH_LAUNCHED_BY',
@@ -698,9 +809,18 @@ def main():
             raise SystemExit(1)
         return
 
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv algos
+    # Deterministic kernel selection: nothing is picked by timing at run time.
+    #   library GEMMs  -> the committed tuning table (iouaware/tuning/hipblaslt_gfx950.json, found
+    #                     offline by tools/tune_gemm.py), else the library heuristic's first result;
+    #   MIOpen convs   -> immediate mode (the library's own ranking, no find-mode timing race).
+    # --miopen-find / --gemm-tune bring the old pick-by-timing behaviour back for comparisons.
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    # (MIOpen's "deterministic" attribute is not an option: it leaves only the naive kernel, 25-64 ms
+    # per convolution.  The strided convolutions whose fast library kernels add split-K partial
+    # sums with atomics run as im2col / strided-batched GEMMs instead, csrc/im2col.hip; what is
+    # left on MIOpen in the fp32 path is the 7x7 stem, whose immediate-mode kernel does not split.)
     from iouaware import ops
-    ops.gemm_tuning('all')          # library GEMMs: time every supporting kernel per shape (+2 %)
+    ops.gemm_tuning(args.gemm_tune)
 
     cfg_name, backbone, batch, dtype_name = CONFIGS[args.config]
     if args.config == 'r50-train':
@@ -745,6 +865,8 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'fp32' if esz == 4 else 'bf16', 'data': 'synthetic',
+            'kernel_selection': {'gemm': dict(mode=args.gemm_tune, **ops.gemm_table_stats()),
+                                 'miopen': 'find mode' if args.miopen_find else 'immediate mode (stem only)'},
             'config': {'workload': ('IoU-aware RetinaNet R-50-FPN fp32, batch 8 per GPU, '
                                     '3x800x1344 (1333x800 padded to /32), random-init weights, '
                                     'whole inference path incl. NMS') if headline else
@@ -775,7 +897,7 @@ def main():
                          'wino': wino},
         }
         if world == 1 and headline and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, stepper)
+            out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None
         if world == 1 and not args.no_pipeline:

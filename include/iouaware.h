@@ -322,12 +322,57 @@ int ia_linear_bias_act_bf16(const void *A, const void *W, const float *bias, con
 int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows, int k, int n,
                     void *workspace, size_t workspace_bytes, void *stream);
 
-/* How many candidates the first call of a GEMM shape times: 0 = the library heuristic's top 16
- * (default; or 1 when the environment has IA_GEMM_TUNE=all at the first GEMM), 1 = every kernel of
- * the library that supports the problem (~250 for fp32, ~0.3 s per shape; +2 % img/s on the R-50
- * inference step).  Shapes already chosen keep their choice.  Returns the previous mode; any other
- * argument only queries.                                                                        */
+/* Convolutions with a stride as plain contractions with a FIXED reduction order (the library
+ * convolution's fast fp32 channels-last kernels for these shapes split the reduction and add the
+ * partial sums with atomics: other bits in every run).
+ *   ia_im2col3x3_nhwc  3x3 / pad 1 / stride s (1..4) taps of a channels-last (B, H, W, C) tensor as
+ *     the row-major matrix col[(b, yo, xo)][tap * C + c] (zeros outside the image), tap = dy * 3 + dx,
+ *     Ho = (H - 1) / s + 1; C * sizeof(dtype) must be a multiple of 16.  ia_im2col3x3_bytes: its size.
+ *     The convolution is then ia_linear_bias_act[_bf16] with rows = B * Ho * Wo, k = 9 * C and the
+ *     weight stored (9 * C, Cout): folded BatchNorm / bias / ReLU in the GEMM epilogue.  Replaces
+ *     conv2 (stride 2) of the first bottleneck of ResNet stages 2-4 (resnet.py:147-160) and the
+ *     FPN's P6 / P7 (necks/fpn.py:84-99) at inference.
+ *   ia_conv1x1_strided  1x1 / stride s on a channels-last (B, H, W, k) tensor -> (B, Ho, Wo, n):
+ *     D = act(x[:, ::s, ::s, :] . W_kn + bias + residual) as one strided-batched library GEMM that
+ *     reads the input in place (leading dimension s * k; one batch item per output row); the
+ *     projection shortcut of those blocks (resnet.py:436-449).  dtype IA_F32 / IA_BF16.          */
+size_t ia_im2col3x3_bytes(int B, int H, int W, int C, int stride, int dtype);
+int ia_im2col3x3_nhwc(const void *x, void *col, int B, int H, int W, int C, int stride, int dtype,
+                      void *stream);
+int ia_conv1x1_strided(const void *x, const void *W_kn, const float *bias, const void *residual,
+                       void *D, int B, int H, int W, int k, int n, int stride, int relu, int dtype,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* How the library kernel of a new GEMM shape is chosen.
+ *   2  FROZEN (default): the entry of the tuning table below, else the library heuristic's first
+ *      result.  Nothing is timed at run time, so a process computes the same bits in every run
+ *      (pick-by-timing made the arithmetic depend on the winner of a race).
+ *   0 / 1  OFFLINE tuning (tools/tune_gemm.py writes the table with them): the first call of a
+ *      shape times the heuristic's top 16 / every kernel of the library that supports the problem
+ *      (~250 for fp32, ~0.3 s per shape; +2 % img/s on the R-50 inference step).
+ * The environment variable IA_GEMM_TUNE = heuristic | all selects 0 / 1 at the first GEMM.  Shapes
+ * already resolved keep their kernel.  Returns the previous mode; any other argument only queries. */
 int ia_gemm_tuning(int mode);
+
+/* The tuning table: (m, n, k, flags, batch, dtype) in the column-major terms of csrc/gemm.hip ->
+ * the library's solution index (hipblaslt_ext::getIndexFromAlgo).  The package ships the table
+ * measured on MI355X (iouaware/tuning/hipblaslt_gfx950.json, loaded by iouaware.ops at the first
+ * GEMM together with the library version it was measured with; a table from another library
+ * version is ignored, a solution the library no longer offers for the problem counts as stale
+ * and the heuristic's first result is used).
+ *   ia_gemm_table_add    one entry (a shape already resolved is resolved again);
+ *   ia_gemm_table_clear  drops the table AND every resolved shape;
+ *   ia_gemm_table_dump   the solution index in use for every shape resolved so far, rows of
+ *                        7 x int64 {m, n, k, flags, batch, dtype, index}; returns the number of
+ *                        shapes (rows7 may be NULL to query);
+ *   ia_gemm_table_stats  {shapes served by the table, by the heuristic, stale entries};
+ *   ia_gemm_library_version  hipblasLtGetVersion of the library mapped into this process.      */
+int ia_gemm_table_add(int64_t m, int64_t n, int64_t k, int flags, int batch, int dtype,
+                      int solution_index);
+int ia_gemm_table_clear(void);
+int ia_gemm_table_dump(int64_t *rows7, int capacity);
+int ia_gemm_table_stats(int64_t *hits_misses_stale);
+int ia_gemm_library_version(void);
 
 /* Training forms of the same library GEMM (convolution autograd nodes, iouaware/train_fuse.py):
  *   ia_linear_bias_act_wt: as ia_linear_bias_act with the weight stored (n, k) row-major -- the

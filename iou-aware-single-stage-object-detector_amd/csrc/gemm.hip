@@ -30,10 +30,18 @@ struct LtState {
     // may overlap on different streams must not share one
     std::map<hipStream_t, hipblasLtHandle_t> handles;
     std::mutex mu;
-    std::map<std::tuple<int64_t, int64_t, int64_t, int, int, int>, hipblasLtMatmulAlgo_t> algos;
-    // candidates timed at the first call of a shape: 0 = the heuristic's top 16, 1 = every kernel of
-    // the library that supports the problem (~250 for fp32: ~0.3 s per shape, +2 % img/s on R-50)
+    typedef std::tuple<int64_t, int64_t, int64_t, int, int, int> Key;     // m, n, k, flags, batch, dtype
+    std::map<Key, hipblasLtMatmulAlgo_t> algos;
+    // How the kernel of a new shape is chosen.  2 (the default) = FROZEN: the entry of the tuning
+    // table (ia_gemm_table_add: library solution indices found offline by tools/tune_gemm.py and
+    // committed with the package), else the library heuristic's first result -- nothing is timed, so
+    // the same process on the same library computes the same bits in every run.  0 / 1 are the
+    // OFFLINE modes that write the table: time the heuristic's top 16 / every kernel of the library
+    // that supports the problem (~250 for fp32: ~0.3 s per shape) at the first call of a shape.
     int tuning = -1;
+    std::map<Key, int> table;          // shape -> library solution index (frozen mode)
+    std::map<Key, int> chosen;         // shape -> solution index in use (ia_gemm_table_dump)
+    long table_hits = 0, table_misses = 0, table_stale = 0;
 };
 
 static LtState &lt_state()
@@ -51,7 +59,7 @@ static int lt_status(hipblasStatus_t s) { return s == HIPBLAS_STATUS_SUCCESS ? 0
 static int lt_gemm(int transa, int transb, int64_t m, int64_t n, int64_t k, const void *A, int64_t lda,
                    int64_t sa, const void *B, int64_t ldb, int64_t sb, const float *bias,
                    const void *residual, void *D, int64_t ldd, int64_t sd, int relu, int batch,
-                   int dtype, void *workspace, size_t workspace_bytes, void *stream)
+                   int dtype, void *workspace, size_t workspace_bytes, void *stream, int tag = 0)
 {
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
     const hipDataType dt = (dtype == IA_F32) ? HIP_R_32F : HIP_R_16BF;
@@ -105,9 +113,44 @@ static int lt_gemm(int transa, int transb, int64_t m, int64_t n, int64_t k, cons
     const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
     const void *C = residual ? residual : D;
     const int flags = (bias ? 1 : 0) | (relu ? 2 : 0) | (residual ? 4 : 0) | (transa ? 8 : 0) |
-                      (transb ? 16 : 0);
+                      (transb ? 16 : 0) | (tag << 5);
     const auto key = std::make_tuple(m, n, k, flags, batch, dtype);
     auto it = st.algos.find(key);
+    if (st.tuning < 0) {
+        const char *tune = getenv("IA_GEMM_TUNE");
+        st.tuning = (tune && !strcmp(tune, "all")) ? 1 : (tune && !strcmp(tune, "heuristic")) ? 0 : 2;
+    }
+    if (it == st.algos.end() && st.tuning == 2) {
+        // frozen: the committed table's solution when the library still has it for this problem
+        auto te = st.table.find(key);
+        if (te != st.table.end()) {
+            std::vector<int> idx(1, te->second);
+            std::vector<hipblasLtMatmulHeuristicResult_t> one;
+            size_t need = 0;
+            if (hipblaslt_ext::getAlgosFromIndex(handle, idx, one) == HIPBLAS_STATUS_SUCCESS && one.size() == 1 &&
+                hipblaslt_ext::matmulIsAlgoSupported(handle, desc, &alpha, la, lb, &beta, lc, lc, one[0].algo,
+                                                     need) == HIPBLAS_STATUS_SUCCESS &&
+                need <= workspace_bytes) {
+                it = st.algos.emplace(key, one[0].algo).first;
+                st.chosen[key] = te->second;
+                ++st.table_hits;
+            } else {
+                ++st.table_stale;
+            }
+        }
+        if (it == st.algos.end()) {
+            IA_LT(hipblasLtMatmulPreferenceCreate(&pref));
+            IA_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                        &workspace_bytes, sizeof(workspace_bytes)));
+            hipblasLtMatmulHeuristicResult_t first;
+            int nres = 0;
+            IA_LT(hipblasLtMatmulAlgoGetHeuristic(handle, desc, la, lb, lc, lc, pref, 1, &first, &nres));
+            if (nres < 1) { cleanup(); return IA_E_ARG; }
+            it = st.algos.emplace(key, first.algo).first;
+            st.chosen[key] = hipblaslt_ext::getIndexFromAlgo(first.algo);
+            ++st.table_misses;
+        }
+    }
     if (it == st.algos.end()) {
         IA_LT(hipblasLtMatmulPreferenceCreate(&pref));
         IA_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
@@ -116,10 +159,6 @@ static int lt_gemm(int transa, int transb, int64_t m, int64_t n, int64_t k, cons
         int nres = 0;
         IA_LT(hipblasLtMatmulAlgoGetHeuristic(handle, desc, la, lb, lc, lc, pref, 16, res.data(), &nres));
         res.resize(nres > 0 ? nres : 0);
-        if (st.tuning < 0) {
-            const char *tune = getenv("IA_GEMM_TUNE");
-            st.tuning = (tune && !strcmp(tune, "all")) ? 1 : 0;
-        }
         if (st.tuning == 1) {
             // every kernel of the library that supports the problem, not only the heuristic's top 16
             std::vector<hipblasLtMatmulHeuristicResult_t> all;
@@ -161,7 +200,11 @@ static int lt_gemm(int transa, int transb, int64_t m, int64_t n, int64_t k, cons
             float best_ms = 1e30f;
             for (size_t i = 0; i < first.size() && i < 8; ++i) {
                 if (first[i].first >= 1e29f) break;
-                const float ms = time_one(first[i].second, 4);
+                // short kernels: enough runs for ~0.5 ms between the events (a 30 us kernel timed
+                // over 4 runs is decided by launch jitter)
+                int runs = first[0].first > 0.f ? (int)(0.5f / first[0].first) : 4;
+                runs = runs < 4 ? 4 : (runs > 64 ? 64 : runs);
+                const float ms = time_one(first[i].second, runs);
                 if (ms < best_ms) { best_ms = ms; best = first[i].second; }
             }
             if (getenv("IA_GEMM_TUNE_VERBOSE"))
@@ -171,6 +214,7 @@ static int lt_gemm(int transa, int transb, int64_t m, int64_t n, int64_t k, cons
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
         it = st.algos.emplace(key, res[best].algo).first;
+        st.chosen[key] = hipblaslt_ext::getIndexFromAlgo(res[best].algo);
     }
     rc = ia::lt_status(hipblasLtMatmul(handle, desc, &alpha, A, la, B, lb, &beta, C, lc, D, lc,
                                        &it->second, workspace, workspace_bytes, s));
@@ -211,6 +255,34 @@ extern "C" int ia_linear_bias_act_bf16(const void *A, const void *W, const float
                          workspace_bytes, stream);
 }
 
+/* 1x1 convolution with a stride on a channels-last activation (the projection shortcut of the
+ * first block of ResNet stages 2-4, resnet.py:436-449) as ONE strided-batched library GEMM -- no
+ * gather copy: batch item (b, yo) = output row yo of image b; its Wo input pixels lie `stride`
+ * pixels apart (leading dimension stride * k) and consecutive batch items stride * W * k apart
+ * (images are contiguous and H % stride == 0, so the item index runs through the images).        */
+extern "C" int ia_conv1x1_strided(const void *x, const void *W_kn, const float *bias, const void *residual,
+                                  void *D, int B, int H, int W, int k, int n, int stride, int relu,
+                                  int dtype, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 1 || H < 1 || W < 1 || k < 1 || n < 1 || stride < 1) return IA_E_ARG;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t esz = dtype == IA_F32 ? 4 : 2;
+    if (H % stride == 0)
+        return ia::lt_gemm(0, 0, n, Wo, k, W_kn, n, 0, x, (int64_t)stride * k, (int64_t)stride * W * k, bias,
+                           residual, D, n, (int64_t)Wo * n, relu, B * Ho, dtype, workspace, workspace_bytes,
+                           stream, 1);
+    for (int b = 0; b < B; ++b) {          // rows of the next image do not continue the item stride
+        const char *xb = (const char *)x + (size_t)b * H * W * k * esz;
+        const char *rb = residual ? (const char *)residual + (size_t)b * Ho * Wo * n * esz : nullptr;
+        char *db = (char *)D + (size_t)b * Ho * Wo * n * esz;
+        int rc = ia::lt_gemm(0, 0, n, Wo, k, W_kn, n, 0, xb, (int64_t)stride * k, (int64_t)stride * W * k,
+                             bias, rb, db, n, (int64_t)Wo * n, relu, Ho, dtype, workspace, workspace_bytes,
+                             stream, 1);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows,
                                int k, int n, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -241,7 +313,74 @@ extern "C" int ia_gemm_tuning(int mode)
 {
     ia::LtState &st = ia::lt_state();
     std::lock_guard<std::mutex> lock(st.mu);
-    const int prev = st.tuning < 0 ? 0 : st.tuning;
-    if (mode == 0 || mode == 1) st.tuning = mode;
+    const int prev = st.tuning < 0 ? 2 : st.tuning;
+    if (mode >= 0 && mode <= 2) st.tuning = mode;
     return prev;
+}
+
+/* ---- the tuning table (include/iouaware.h) ---- */
+extern "C" int ia_gemm_table_clear(void)
+{
+    ia::LtState &st = ia::lt_state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    st.table.clear();
+    st.algos.clear();
+    st.chosen.clear();
+    st.table_hits = st.table_misses = st.table_stale = 0;
+    return 0;
+}
+
+extern "C" int ia_gemm_table_add(int64_t m, int64_t n, int64_t k, int flags, int batch, int dtype,
+                                 int solution_index)
+{
+    if (m < 1 || n < 1 || k < 1 || batch < 1 || solution_index < 0) return IA_E_ARG;
+    ia::LtState &st = ia::lt_state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    const auto key = std::make_tuple(m, n, k, flags, batch, dtype);
+    st.table[key] = solution_index;
+    st.algos.erase(key);               // a shape already resolved is resolved again from the table
+    st.chosen.erase(key);
+    return 0;
+}
+
+extern "C" int ia_gemm_table_dump(int64_t *rows7, int capacity)
+{
+    ia::LtState &st = ia::lt_state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    int i = 0;
+    for (auto &e : st.chosen) {
+        if (rows7 && i < capacity) {
+            int64_t *r = rows7 + (size_t)i * 7;
+            r[0] = std::get<0>(e.first); r[1] = std::get<1>(e.first); r[2] = std::get<2>(e.first);
+            r[3] = std::get<3>(e.first); r[4] = std::get<4>(e.first); r[5] = std::get<5>(e.first);
+            r[6] = e.second;
+        }
+        ++i;
+    }
+    return i;
+}
+
+extern "C" int ia_gemm_table_stats(int64_t *hits_misses_stale)
+{
+    ia::LtState &st = ia::lt_state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (!hits_misses_stale) return IA_E_ARG;
+    hits_misses_stale[0] = st.table_hits;
+    hits_misses_stale[1] = st.table_misses;
+    hits_misses_stale[2] = st.table_stale;
+    return 0;
+}
+
+extern "C" int ia_gemm_library_version(void)
+{
+    ia::LtState &st = ia::lt_state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    hipblasLtHandle_t h = nullptr;
+    for (auto &e : st.handles) if (e.second) { h = e.second; break; }
+    bool own = false;
+    if (!h) { if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) return -1; own = true; }
+    int v = -1;
+    if (hipblasLtGetVersion(h, &v) != HIPBLAS_STATUS_SUCCESS) v = -1;
+    if (own) hipblasLtDestroy(h);
+    return v;
 }

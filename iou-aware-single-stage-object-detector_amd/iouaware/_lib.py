@@ -130,6 +130,14 @@ SIGNATURES = {
     'ia_batched_gemm': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     'ia_linear_bias_act_wt': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_gemm_tuning': (_i, [_i]),
+    'ia_im2col3x3_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'ia_im2col3x3_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ia_conv1x1_strided': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'ia_gemm_table_add': (_i, [_i64, _i64, _i64, _i, _i, _i, _i]),
+    'ia_gemm_table_clear': (_i, []),
+    'ia_gemm_table_dump': (_i, [_vp, _i]),
+    'ia_gemm_table_stats': (_i, [_vp]),
+    'ia_gemm_library_version': (_i, []),
     'ia_gemm_tn': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     'ia_focal_loss_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     'ia_focal_loss_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),

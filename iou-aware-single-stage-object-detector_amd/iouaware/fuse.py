@@ -130,6 +130,11 @@ def _bottleneck_forward(self, x):
     elif wino is not None and wino.usable(out):
         # (conv1's BN + ReLU on load,) conv2 + its folded BN + ReLU in the Winograd path
         out = wino(out, pre=pre)
+    elif lt and 'im2col2' in f and out.is_contiguous(memory_format=torch.channels_last):
+        # stride-2 conv2 (first block of stages 2-4): im2col + library GEMM, folded BN + ReLU in
+        # the epilogue -- a fixed reduction order, where the library convolution's split-K kernels
+        # add with atomics (csrc/im2col.hip)
+        out = ops.conv3x3_im2col(out, w['im2col2'], f['b2'], stride=self.conv2.stride[0], relu=True)
     else:
         if pre is not None:
             out = ops.channel_affine_act_(out, f['s1'], f['b1'], relu=True)
@@ -141,7 +146,10 @@ def _bottleneck_forward(self, x):
             idn = ops.linear_bias_act(x, w['wd'], f['b3d'])
             return ops.linear_bias_act(out, w['w3'], None, residual=idn, relu=True)
         ds = self.downsample[0]
-        idn = F.conv2d(x, w['wd_conv'], None, ds.stride, ds.padding)
+        if 'wd_s' in f:                   # strided projection: one strided-batched GEMM, input read in place
+            idn = ops.conv1x1_strided(x, w['wd_s'], None, None, stride=ds.stride[0])
+        else:
+            idn = F.conv2d(x, w['wd_conv'], None, ds.stride, ds.padding)
         return ops.linear_bias_act(out, w['w3'], f['b3d'], residual=idn, relu=True)
     out = self.conv3(out)
     if self.downsample is None:
@@ -160,7 +168,7 @@ def _weights_for(f, dtype):
     w = cache.get(dtype)
     if w is None:
         w = cache[dtype] = {k: v.to(dtype) for k, v in f.items()
-                            if k in ('w1', 'w3', 'wd', 'wd_conv', 'w_kn')}
+                            if k in ('w1', 'w3', 'wd', 'wd_conv', 'wd_s', 'w_kn', 'im2col2', 'im2col')}
     return w
 
 
@@ -226,6 +234,10 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     if 'w_kn' in f and norm and x.dtype in (torch.float32, torch.bfloat16) \
             and x.is_contiguous(memory_format=torch.channels_last):
         return ops.linear_bias_act(x, _weights_for(f, x.dtype)['w_kn'], f['b_kn'], relu=relu)
+    if 'im2col' in f and x.dtype in (torch.float32, torch.bfloat16) \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        return ops.conv3x3_im2col(x, _weights_for(f, x.dtype)['im2col'], f.get('bias'),
+                                  stride=self.conv.stride[0], relu=relu)
     if self.with_norm and norm:
         y = self.conv(x)                      # conv before a norm has no bias
         return ops.channel_affine_act_(y, f['s'], f['b'], relu=relu)
@@ -313,6 +325,14 @@ def _wino_ok(conv):
             and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0)
 
 
+def _im2col_ok(conv):
+    """3x3 / pad 1 with a stride > 1: the im2col + GEMM route (csrc/im2col.hip)"""
+    return (tuple(conv.kernel_size) == (3, 3) and conv.stride[0] == conv.stride[1]
+            and 2 <= conv.stride[0] <= 4 and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.in_channels % 8 == 0
+            and getattr(conv, 'padding_mode', 'zeros') == 'zeros')
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -350,6 +370,9 @@ def _fold(m):
                     f['b3d'] = (f['b3'] + f['bd']).contiguous()
                     if _gemm_ok(ds):
                         f['wd'] = kn(ds, f['sd'])
+                    elif tuple(ds.kernel_size) == (1, 1) and tuple(ds.padding) == (0, 0) \
+                            and ds.groups == 1 and ds.bias is None and ds.stride[0] == ds.stride[1]:
+                        f['wd_s'] = kn(ds, f['sd'])
                     else:
                         f['wd_conv'] = (ds.weight.float() * f['sd'].view(-1, 1, 1, 1)).contiguous(
                             memory_format=torch.channels_last)
@@ -361,6 +384,8 @@ def _fold(m):
                 and c2.in_channels // c2.groups in (4, 8, 16, 32) \
                 and c2.in_channels % (32 if c2.in_channels // c2.groups == 32 else 16) == 0:
             f['gconv2'] = ops.pack_grouped_weight(c2.weight, f['s2'])     # BN scale folded in
+        if winograd and _im2col_ok(c2) and c2.bias is None and 'w1' in f:
+            f['im2col2'] = ops.conv3x3_weight_kn(c2.weight, f['s2'])         # BN scale folded in
         if winograd and _wino_ok(m.conv2) and m.conv2.bias is None:
             from .winograd import WinogradConv3x3
             with torch.no_grad():           # BN scale folded into the weights, shift = bias
@@ -402,6 +427,8 @@ def _fold(m):
                 else:
                     f['w_kn'] = w.t().contiguous()
                     f['b_kn'] = None if c.bias is None else c.bias.detach().float().contiguous()
+        if winograd and not m.with_norm and _im2col_ok(c):
+            f['im2col'] = ops.conv3x3_weight_kn(c.weight)                    # P6 / P7
         if winograd and fpn_conv and not m.with_norm and _wino_ok(m.conv):
             from .winograd import WinogradConv3x3
             f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)

@@ -6,6 +6,7 @@ torch stream and returns device tensors.  No function has a CPU path: tensors
 must live on a ROCm device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -643,6 +644,7 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
                                                 B * H * W, k, n, int(bool(relu)), _stream()),
                    'ia_conv1x1_stream')
         return out
+    _ensure_gemm_table()
     ws = _workspace(x.device, _LT_WS_BYTES)
     if x.dtype == torch.bfloat16:
         if w_nk:
@@ -655,6 +657,88 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
     fn = _lib.lib().ia_linear_bias_act_wt if w_nk else _lib.lib().ia_linear_bias_act
     _lib.check(fn(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out), B * H * W, k, n,
                   int(bool(relu)), _ptr(ws), _LT_WS_BYTES, _stream()), 'ia_linear_bias_act')
+    return out
+
+
+_col_cache = {}
+
+
+def _col_buffer(device, nbytes):
+    """the im2col matrix of conv3x3_im2col: one growing buffer per (device, stream)"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _col_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _col_cache.pop(key, None)
+        buf = _col_cache[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
+
+def conv3x3_im2col(x, w_kn, bias=None, stride=2, relu=False):
+    """3x3 / pad 1 / stride `stride` convolution of a channels-last (B, C, H, W) fp32 / bf16 tensor
+    as im2col (csrc/im2col.hip) + one library GEMM with bias / ReLU in the epilogue: a contraction
+    with a fixed reduction order (the library convolution's split-K kernels for these shapes add
+    with atomics and give other bits in every run).  w_kn: (9 * C, Cout) row-major, row index
+    (dy * 3 + dx) * C + c -- `conv3x3_weight_kn(weight)`."""
+    _require_gpu(x, 'x')
+    B, Cc, H, W = x.shape
+    n = int(w_kn.shape[1])
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('conv3x3_im2col needs a channels-last fp32 / bf16 activation')
+    if tuple(w_kn.shape) != (9 * Cc, n) or not w_kn.is_contiguous() or w_kn.dtype != x.dtype:
+        raise ValueError('weight must be a contiguous (9 * C, Cout) matrix of the activation dtype')
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError('bias must be fp32')
+    dt = _dtype_code(x)
+    L = _lib.lib()
+    nbytes = L.ia_im2col3x3_bytes(B, H, W, Cc, int(stride), dt)
+    if nbytes == 0 or (Cc * x.element_size()) % 16:
+        raise ValueError('conv3x3_im2col: C * sizeof(dtype) must be a multiple of 16')
+    col = _col_buffer(x.device, nbytes)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    _lib.check(L.ia_im2col3x3_nhwc(_ptr(x), _ptr(col), B, H, W, Cc, int(stride), dt, _stream()),
+               'ia_im2col3x3_nhwc')
+    out = torch.empty((B, n, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ensure_gemm_table()
+    ws = _workspace(x.device, _LT_WS_BYTES)
+    fn = L.ia_linear_bias_act if x.dtype == torch.float32 else L.ia_linear_bias_act_bf16
+    _lib.check(fn(_ptr(col), _ptr(w_kn), _ptr(bias), None, _ptr(out), B * Ho * Wo, 9 * Cc, n,
+                  int(bool(relu)), _ptr(ws), _LT_WS_BYTES, _stream()), 'ia_linear_bias_act (im2col)')
+    return out
+
+
+def conv3x3_weight_kn(weight, scale=None):
+    """(Cout, Cin, 3, 3) convolution weight (x per-output-channel scale) -> the (9 * Cin, Cout) GEMM
+    operand of conv3x3_im2col: row (dy * 3 + dx) * Cin + c"""
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale.view(-1, 1, 1, 1)
+    return w.permute(2, 3, 1, 0).reshape(9 * w.shape[1], w.shape[0]).contiguous()
+
+
+def conv1x1_strided(x, w_kn, bias=None, residual=None, stride=2, relu=False):
+    """1x1 / stride-s convolution of a channels-last (B, k, H, W) tensor -> (B, n, Ho, Wo):
+    relu?(x[:, :, ::s, ::s] . w_kn + bias + residual) as one strided-batched library GEMM reading
+    the input in place (csrc/gemm.hip, ia_conv1x1_strided)."""
+    _require_gpu(x, 'x')
+    B, k, H, W = x.shape
+    n = int(w_kn.shape[1])
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError('conv1x1_strided needs a channels-last fp32 / bf16 activation')
+    if tuple(w_kn.shape) != (k, n) or not w_kn.is_contiguous() or w_kn.dtype != x.dtype:
+        raise ValueError('weight must be a contiguous (k, n) matrix of the activation dtype')
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError('bias must be fp32')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((B, n, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('residual must be a channels-last tensor of the output shape and dtype')
+    _ensure_gemm_table()
+    ws = _workspace(x.device, _LT_WS_BYTES)
+    _lib.check(_lib.lib().ia_conv1x1_strided(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out),
+                                             B, H, W, k, n, int(stride), int(bool(relu)), _dtype_code(x),
+                                             _ptr(ws), _LT_WS_BYTES, _stream()), 'ia_conv1x1_strided')
     return out
 
 
@@ -681,11 +765,86 @@ def conv1x1_stream(x, w_kn, bias=None, residual=None, relu=False):
 
 
 def gemm_tuning(mode=None):
-    """'all': the first call of every new GEMM shape times every library kernel that supports it
-    (~0.3 s per shape); 'heuristic': the library heuristic's top 16 (default).  Returns the mode
-    in force before the call; None only queries."""
-    code = {'heuristic': 0, 'all': 1, None: -1}[mode]
-    return ('heuristic', 'all')[_lib.lib().ia_gemm_tuning(code)]
+    """How the library kernel of a new GEMM shape is chosen (csrc/gemm.hip):
+      'frozen' (default)  the committed tuning table, else the library heuristic's first result --
+                          nothing is timed, the same bits in every run;
+      'heuristic' / 'all' OFFLINE tuning: the first call of a shape times the heuristic's top 16 /
+                          every library kernel that supports it (~0.3 s per shape).
+    Returns the mode in force before the call; None only queries."""
+    _ensure_gemm_table()
+    code = {'heuristic': 0, 'all': 1, 'frozen': 2, None: -1}[mode]
+    return ('heuristic', 'all', 'frozen')[_lib.lib().ia_gemm_tuning(code)]
+
+
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'hipblaslt_gfx950.json')
+_gemm_table_state = None
+
+
+def gemm_table_load(path=None, strict_version=True):
+    """Install a tuning table written by `gemm_table_save` (tools/tune_gemm.py).  Entries measured
+    with another hipBLASLt version are ignored (solution indices belong to a library build).
+    -> dict(path, entries, library_version, table_version, used)"""
+    import json
+    global _gemm_table_state
+    path = path or GEMM_TABLE
+    L = _lib.lib()
+    L.ia_gemm_table_clear()
+    state = dict(path=path, entries=0, library_version=L.ia_gemm_library_version(),
+                 table_version=None, used=False)
+    if os.path.exists(path):
+        with open(path) as fh:
+            tab = json.load(fh)
+        state['table_version'] = tab.get('hipblaslt_version')
+        if not strict_version or state['table_version'] == state['library_version']:
+            for e in tab['entries']:
+                _lib.check(L.ia_gemm_table_add(*[int(v) for v in e[:7]]), 'ia_gemm_table_add')
+            state['entries'], state['used'] = len(tab['entries']), True
+    _gemm_table_state = state
+    return state
+
+
+def _ensure_gemm_table():
+    if _gemm_table_state is None:
+        gemm_table_load()
+
+
+def gemm_table_dump():
+    """[(m, n, k, flags, batch, dtype, solution index)] of every GEMM shape resolved so far"""
+    L = _lib.lib()
+    n = L.ia_gemm_table_dump(None, 0)
+    buf = np.zeros((max(n, 1), 7), np.int64)
+    n = L.ia_gemm_table_dump(buf.ctypes.data, int(buf.shape[0]))
+    return [tuple(int(v) for v in r) for r in buf[:n]]
+
+
+def gemm_table_stats():
+    """dict(hits=, misses=, stale=): shapes served by the table / by the heuristic's first result /
+    table entries the library no longer supports"""
+    buf = np.zeros(3, np.int64)
+    _lib.check(_lib.lib().ia_gemm_table_stats(buf.ctypes.data), 'ia_gemm_table_stats')
+    return dict(hits=int(buf[0]), misses=int(buf[1]), stale=int(buf[2]),
+                **{k: v for k, v in (_gemm_table_state or {}).items() if k != 'path'})
+
+
+def gemm_table_save(path=None, merge=True):
+    """write the solutions in use to a table file (offline tuning); merge=True keeps the entries
+    of an existing file for shapes this process did not run"""
+    import json
+    path = path or GEMM_TABLE
+    ver = _lib.lib().ia_gemm_library_version()
+    rows = {r[:6]: r[6] for r in gemm_table_dump()}
+    if merge and os.path.exists(path):
+        with open(path) as fh:
+            old = json.load(fh)
+        if old.get('hipblaslt_version') == ver:
+            for e in old['entries']:
+                rows.setdefault(tuple(int(v) for v in e[:6]), int(e[6]))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as fh:
+        json.dump(dict(hipblaslt_version=ver, arch='gfx950',
+                       key='m, n, k, flags, batch, dtype (column-major terms of csrc/gemm.hip), solution index',
+                       entries=[list(k) + [v] for k, v in sorted(rows.items())]), fh, indent=0)
+    return len(rows)
 
 
 def gemm_tn(g, x):
@@ -701,6 +860,7 @@ def gemm_tn(g, x):
     rows, n, k = int(g.shape[-2]), int(g.shape[-1]), int(x.shape[-1])
     out = torch.empty(((batch, n, k) if g.dim() == 3 else (n, k)), dtype=torch.float32,
                       device=g.device)
+    _ensure_gemm_table()
     ws = _workspace(g.device, _LT_WS_BYTES)
     _lib.check(_lib.lib().ia_gemm_tn(_ptr(g), _ptr(x), _ptr(out), batch, rows, n, k, _ptr(ws),
                                      _LT_WS_BYTES, _stream()), 'ia_gemm_tn')

@@ -143,8 +143,11 @@ _LT_WS_BYTES = 128 << 20
 
 
 def batched_gemm(v, u, out):
-    """out[b] = v[b] @ u[b] through hipBLASLt (csrc/gemm.hip): the first call of a shape times the
-    library's candidate kernels, which is worth ~20 % over the default pick at these shapes"""
+    """out[b] = v[b] @ u[b] through hipBLASLt (csrc/gemm.hip); the kernel of a shape comes from the
+    committed tuning table (ops.gemm_table_load: found offline by timing the library's candidates,
+    worth ~20 % over the heuristic's pick at these shapes), never from a timing race at run time"""
+    from . import ops
+    ops._ensure_gemm_table()
     batch, rows, k = v.shape
     n = u.shape[2]
     if not (v.is_contiguous() and u.is_contiguous() and out.is_contiguous()):

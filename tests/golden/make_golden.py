@@ -677,20 +677,30 @@ def gen_e2e():
 
 # ---------------------------------------------------------------- deeper backbones (configs 3, 4)
 E2E_BACKBONES = (
-    # name, reference config file, backbone overrides
-    ('r101', 'iou_aware_retinanet_r101_fpn_1x_4gpu.py', {}),
-    ('x101_32x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', {}),
-    ('x101_64x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', dict(groups=64, base_width=4)),
+    # name, reference config file, backbone overrides, (image seed, pad h, pad w, img h, img w)
+    ('r101', 'iou_aware_retinanet_r101_fpn_1x_4gpu.py', {}, (9, 256, 320, 250, 317)),
+    ('x101_32x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', {}, (9, 256, 320, 250, 317)),
+    ('x101_64x4d', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py', dict(groups=64, base_width=4),
+     (9, 256, 320, 250, 317)),
+    # BASELINE configs 3 / 4 at the benchmark's size
+    ('r101_full', 'iou_aware_retinanet_r101_fpn_1x_4gpu.py', {}, (12, 800, 1344, 800, 1333)),
+    ('x101_64x4d_full', 'iou_aware_retinanet_x101_32x4d_fpn_1x_4gpu.py',
+     dict(groups=64, base_width=4), (13, 800, 1344, 800, 1333)),
 )
 
 
-def gen_e2e_backbones():
+def gen_e2e_backbones(only=None):
     """R-101 (BASELINE config 3's backbone) and ResNeXt-101 32x4d / 64x4d (config 4: the 32x4d
     config file of the reference with groups=64, as retinanet_x101_64x4d_fpn_1x.py sets them):
-    the reference detector on the trained-like weights, one 256x320 image through its test-time
-    call -- sampled head logits and the per-class result arrays."""
+    the reference detector on the trained-like weights, one image (256x320, and 800x1344 for the
+    two BASELINE backbones) through its test-time call -- sampled head logits and the per-class
+    result arrays, TWICE: as the reference computes them (fp32, oneDNN on this CPU) and with the
+    same reference modules converted to fp64 (`*64` keys: the "true" convolution values, which
+    say whose fp32 rounding a deviation belongs to)."""
     from mmdet.models import build_detector
-    for name, cfile, over in E2E_BACKBONES:
+    for name, cfile, over, (iseed, ph, pw, ih, iw) in E2E_BACKBONES:
+        if only and name not in only:
+            continue
         rcfg = ref_shim.load_config(ref_shim.REF + '/configs/iou_aware_single_stage_detector/' + cfile)
         rcfg.model['pretrained'] = None
         rcfg.model['backbone'].update(over)
@@ -698,7 +708,7 @@ def gen_e2e_backbones():
         ref = build_detector(rcfg.model, train_cfg=rcfg.train_cfg, test_cfg=rcfg.test_cfg).eval()
         with torch.no_grad():
             synth.e2e_fill_state(ref.state_dict(), 77)
-        iseed, ph, pw, ih, iw, sf = 9, 256, 320, 250, 317, 1.0
+        sf = 1.0
         img = synth.e2e_image(iseed, 1, ph, pw, ih, iw)
         meta = dict(ori_shape=(ih, iw, 3), img_shape=(ih, iw, 3), pad_shape=(ph, pw, 3),
                     scale_factor=sf, flip=False)
@@ -723,9 +733,30 @@ def gen_e2e_backbones():
                 out['%s_val_%d' % (nm, lv)] = a[idx]
         out['result_counts'] = np.array([r.shape[0] for r in result], np.int32)
         out['result_cat'] = np.concatenate(result, 0).astype(np.float32)
+        # the same reference modules in fp64: the fp32 weights / image converted exactly
+        ref64 = ref.double()
+        x64 = x.double()
+        with torch.no_grad():
+            cls64, reg64, iou64 = ref64.bbox_head(ref64.extract_feat(x64))
+            result64 = ref64(return_loss=False, rescale=True, img=[x64], img_meta=[[meta]],
+                             gt_bboxes=[[torch.from_numpy(g).double()]],
+                             gt_labels=[[torch.from_numpy(l)]])
+        assert cls64[0].dtype == torch.float64 and result64[0].dtype == np.float64
+        ref_err = 0.0
+        for nm, ts in (('cls', cls64), ('reg', reg64), ('iou', iou64)):
+            for lv, t in enumerate(ts):
+                v = t.numpy().reshape(-1)[out['%s_idx_%d' % (nm, lv)]]
+                out['%s_val64_%d' % (nm, lv)] = v
+                e = np.abs(out['%s_val_%d' % (nm, lv)].astype(np.float64) - v) / np.maximum(1.0, np.abs(v))
+                ref_err = max(ref_err, float(e.max()))
+        out['result_counts64'] = np.array([r.shape[0] for r in result64], np.int32)
+        out['result_cat64'] = np.concatenate(result64, 0).astype(np.float64)
+        out['ref_logit_err_vs_fp64'] = np.float64(ref_err)
         sc = np.sort(out['result_cat'][:, 4].astype(np.float64))[::-1]
         print('e2e backbone', name, 'dets', int(out['result_counts'].sum()),
-              'min relative score gap %.2e' % float(((sc[:-1] - sc[1:]) / sc[:-1]).min()))
+              'fp64 dets', int(out['result_counts64'].sum()),
+              'min relative score gap %.2e' % float(((sc[:-1] - sc[1:]) / sc[:-1]).min()),
+              'reference fp32 vs its fp64 evaluation, sampled head logits: %.2e' % ref_err)
         save('e2e_backbone_' + name, **out)
 
 
@@ -845,4 +876,8 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones', 'mnms_quirk', 'get_bboxes_vecscale',
                              'losses_mixed_pad']
     for w in which:
-        globals()['gen_' + w]()
+        if ':' in w:                          # e.g. e2e_backbones:r101_full,x101_64x4d_full
+            w, only = w.split(':')
+            globals()['gen_' + w](only.split(','))
+        else:
+            globals()['gen_' + w]()
