@@ -103,11 +103,23 @@ def _match_sets(want, got):
     return matched, total, worst_b, worst_s
 
 
-def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0):
+def _relerr(a, b):
+    """|a - b| / max(1, |b|) per coordinate (the north star's tolerance unit), fp64"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
     """Every reference detection without a counterpart within TOL must have a stated reason, or
     the test fails (round 2 accepted `matched >= total - 2 / - 5` without looking at WHICH ones):
-      near-tol  a detection of the same class differs by at most 2 x TOL in one coordinate: the
-                accumulated fp32 convolution error of ~60-110 layers touches the tolerance;
+      closer-to-truth  (`truth`: the same detector evaluated in fp64, per-class arrays) the
+                own detection is not farther from the fp64 evaluation than max(TOL, what the
+                reference's fp32 result is): |own - truth| <= max(TOL, |ref - truth|) in every
+                coordinate -- the deviation belongs to the reference's own fp32 rounding
+                (VERDICT r3 item 1b: triangulation instead of a widened band);
+      near-tol  a detection of the same class differs by at most `near` (2) x TOL in one
+                coordinate: the accumulated fp32 convolution error of ~60-110 layers touches
+                the tolerance;
       near-cut  its score lies within 8 x the measured head-logit error (relative) of the
                 reference's 100th score: rank 100 / 101 may swap (`gaps`: the fixture's own
                 relative gaps between consecutive survivors, when it stores them).
@@ -120,16 +132,25 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0):
     for c, (w, g) in enumerate(zip(want, got)):
         used = np.zeros(len(g), bool)
         for d in w:
-            err = np.abs(g.astype(np.float64) - d.astype(np.float64)) / np.maximum(1.0, np.abs(d.astype(np.float64))) \
-                if len(g) else np.zeros((0, 5))
+            err = _relerr(g, d) if len(g) else np.zeros((0, 5))
             ok = (err <= TOL).all(1) & ~used if len(g) else np.zeros(0, bool)
             if ok.any():
                 used[int(np.argmax(ok))] = True
                 continue
             rel_to_cut = (float(d[4]) - cut) / max(float(d[4]), 1e-30)
             near = (err.max(1).min() if len(g) else np.inf)
-            near_mult = near_tol_mult
-            if near <= near_mult * TOL:
+            t = truth[c] if truth is not None else np.zeros((0, 5))
+            if len(t) and len(g):
+                tj = t[int(np.argmin(_relerr(t, d).max(1)))]          # the fp64 twin of the reference detection
+                e_ref = _relerr(d, tj)
+                gj = g[int(np.argmin(_relerr(g, tj).max(1)))]
+                e_own = _relerr(gj, tj)
+                if e_ref.max() <= 10 * TOL and (e_own <= np.maximum(TOL, e_ref)).all():
+                    lines.append('class %d score %.4f: own detection off the reference by %.2f x TOL, off the fp64 '
+                                 'evaluation by %.2f x TOL; the REFERENCE is off its own fp64 evaluation by %.2f x '
+                                 'TOL (closer-to-truth)' % (c, d[4], near / TOL, e_own.max() / TOL, e_ref.max() / TOL))
+                    continue
+            if near <= near_tol_mult * TOL:
                 lines.append('class %d score %.4f: nearest own detection off by %.2f x TOL (near-tol)'
                              % (c, d[4], near / TOL))
             elif rel_to_cut <= margin:
@@ -140,6 +161,19 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0):
                              % (c, d[4], d[:4].tolist(), near, rel_to_cut))
                 bad += 1
     return lines, bad
+
+
+def _truth_worst(truth, dets):
+    """worst deviation (x TOL) of `dets` from the fp64 evaluation, over the truth detections that
+    have a same-class counterpart within 10 x TOL"""
+    worst = 0.0
+    for t, g in zip(truth, dets):
+        for tj in t:
+            if len(g):
+                e = _relerr(g, tj).max(1).min()
+                if e <= 10 * TOL:
+                    worst = max(worst, float(e))
+    return worst / TOL
 
 
 _REPORT = []
@@ -308,12 +342,28 @@ def _trained_like(m, seed=11):
 def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
     """R-101 (config 3's backbone) and X-101-64x4d (config 4; its grouped 3x3 convs run on the
     MFMA kernel of csrc/gconv.hip in the channels-last path, reference resnext.py:12-91): fused
-    and Winograd paths vs the module forward, 1e-4."""
+    and Winograd paths vs the module forward, 1e-4 -- and, for the detections, both against the
+    SAME modules evaluated in fp64 on the host (triangulation: a detection of the bench path that
+    is not within TOL of the plain fp32 modules' must be no farther from the fp64 evaluation than
+    max(TOL, what the plain modules are); round 3 accepted 5 x TOL here)."""
+    import copy
     from iouaware.fuse import fuse_inference, unfuse_inference
-    m = _trained_like(_build(backbone)).cuda()
-    x = torch.from_numpy(synth.e2e_image(9, 2, 256, 320, 256, 320)).cuda()
+    m = _trained_like(_build(backbone))
+    x_cpu = torch.from_numpy(synth.e2e_image(9, 2, 256, 320, 256, 320))
     metas = [synth.img_meta(256, 320, 256, 320, 1.0)] * 2
     with torch.no_grad():
+        m64 = copy.deepcopy(m).double()
+        truth_head = m64.bbox_head(m64.extract_feat(x_cpu.double()))
+        del m64
+    m = m.cuda()
+    x = x_cpu.cuda()
+    with torch.no_grad():
+        # the fp64 head outputs, rounded to fp32 ONCE, through the product's post-conv path
+        th = [[t.float().cuda() for t in ts] for ts in truth_head]
+        truth_dets = [m.bbox_head.get_bboxes(*[[t[b:b + 1] for t in ts] for ts in th], None, None,
+                                             metas[b:b + 1], m.test_cfg, True)[0] for b in range(2)]
+        from iouaware.bbox import bbox2result
+        truth_dets = [bbox2result(d, l, 81) for d, l in truth_dets]
         ref = m.forward_head(x)
         ref_dets = m.simple_test_batch(x, metas, rescale=True)
         assert fuse_inference(m) > 0
@@ -332,12 +382,14 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
             for u, v in zip(a, b):
                 e = float(((u - v).abs() / u.abs().clamp(min=1.0)).max())
                 assert e <= TOL, (name, tag, e)
-    for d, d0 in zip(wino_dets, ref_dets):
+    for b, (d, d0, t) in enumerate(zip(wino_dets, ref_dets, truth_dets)):
         matched, total, _, _ = _match_sets(d0, d)
-        # two of this build's own paths (MIOpen picks its algorithms per run): their features agree
-        # within TOL (asserted above); a box edge near 0 px is compared absolutely (max(1, |x|)) and a
-        # 2e-4 px difference after exp(dw) * 400 px anchors is rounding, so: near-tol up to 5 x TOL
-        why, bad = _explain_unmatched(d0, d, TOL, near=5.0)
+        why, bad = _explain_unmatched(d0, d, TOL, near=2.0, truth=t)
+        _REPORT.append('%-10s image %d: bench path vs plain modules %d/%d within 1e-4; off the fp64 evaluation: '
+                       'bench path %.2f x TOL, plain modules %.2f x TOL' % (name, b, matched, total,
+                                                                         _truth_worst(t, d), _truth_worst(t, d0)))
+        for line in why:
+            _REPORT.append('      %s image %d: %s' % (name, b, line))
         assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
 
 
@@ -346,6 +398,9 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
     ('r101', dict(depth=101)),
     ('x101_32x4d', dict(type='ResNeXt', depth=101, groups=32, base_width=4)),
     ('x101_64x4d', dict(type='ResNeXt', depth=101, groups=64, base_width=4)),
+    # BASELINE configs 3 / 4 at the benchmark's size, 800 x 1344
+    ('r101_full', dict(depth=101)),
+    ('x101_64x4d_full', dict(type='ResNeXt', depth=101, groups=64, base_width=4)),
 ])
 def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
     """tests/golden/e2e_backbone_*.npz (`make_golden.py e2e_backbones`): the REFERENCE detector
@@ -382,16 +437,31 @@ def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
                    '(worst box %.2e, score %.2e)' % (name, path, worst, worst / TOL, matched, total,
                                                      wb, ws))
     assert worst <= TOL, (name, path, worst)
-    # ~110 layers: a few box coordinates come within 10 % of the tolerance (0.03 px at x = 300);
-    # a detection that is not matched within TOL must be explained (near-tol, or rank 100 / 101
-    # within the measured logit error) -- no count-based slack.  near-tol here: <= 3 x TOL -- the
-    # library convolutions pick their algorithms per run, and over repeated runs of the SAME code
-    # the worst box of the X-101-64x4d fixture moved between 0.75 and 1.61 x TOL (on the plain
-    # modules as well as on the bench path); the sampled head logits stay below 0.2 x TOL.
-    why, bad = _explain_unmatched(want, result, worst, near=3.0)
+    # the fixture also holds the REFERENCE modules evaluated in fp64 (`*64` keys): sampled logits
+    # and detections.  Whose rounding is a deviation?  |own - truth| against |ref - truth|.
+    worst64 = ref64 = 0.0
+    for nm, ts in (('cls', cls), ('reg', reg), ('iou', iou)):
+        for lv, t in enumerate(ts):
+            a = t.float().contiguous().cpu().numpy().reshape(-1)
+            t64 = f['%s_val64_%d' % (nm, lv)]
+            worst64 = max(worst64, float(_relerr(a[f['%s_idx_%d' % (nm, lv)]], t64).max()))
+            ref64 = max(ref64, float(_relerr(f['%s_val_%d' % (nm, lv)], t64).max()))
+    truth = _split(f['result_cat64'], f['result_counts64'])
+    _REPORT.append('%-10s %-8s vs the fp64 evaluation: head logits own %.2f x TOL, reference %.2f x TOL | detections '
+                   'own %.2f x TOL, reference %.2f x TOL' % (name, path, worst64 / TOL, ref64 / TOL,
+                                                             _truth_worst(truth, result), _truth_worst(truth, want)))
+    # ~110 layers: a detection that is not matched within TOL must be explained -- by the fp64
+    # evaluation (the reference's own fp32 result is at least as far from it), near-tol <= 2 x TOL,
+    # or rank 100 / 101 within the measured logit error -- no count-based slack, no widened band
+    # (round 3: 3 x TOL; the X-101-64x4d reference fixture itself is 0.70 x TOL off its fp64 twin).
+    why, bad = _explain_unmatched(want, result, worst, near=2.0, truth=truth)
     for line in why:
         _REPORT.append('      %s %s: %s' % (name, path, line))
     assert total == 100 and bad == 0 and matched + len(why) == total, (matched, total, why)
+    # (reported, not asserted: the distance of the product path from the fp64 evaluation.  The
+    # north star's bar is the reference; on the 256x320 X-101-64x4d fixture one ill-conditioned
+    # box -- exp(dw) on a 400 px anchor amplifies a 0.15 x TOL logit difference eightfold -- puts
+    # the reference 0.70 and this build 1.26 x TOL from the truth, 0.56 x TOL from each other.)
 
 
 def test_config3_bf16_batch16_post_conv_path(oracle_lib):
@@ -514,3 +584,87 @@ def test_config3_r101_bf16_whole_network():
     # and most of them.
     assert strong > 0 and found >= found_eager - strong // 12 and found >= 0.75 * strong, \
         (strong, found, found_eager)
+
+
+def _twin_retention(ref_classes, mine, score_min=0.3, iou_min=0.85):
+    """of the reference detections with score > score_min: how many have a twin (same class,
+    IoU > iou_min, the +1 pixel convention of the reference) among `mine`"""
+    def iou(a, b):
+        x1, y1 = np.maximum(a[0], b[:, 0]), np.maximum(a[1], b[:, 1])
+        x2, y2 = np.minimum(a[2], b[:, 2]), np.minimum(a[3], b[:, 3])
+        inter = np.clip(x2 - x1 + 1, 0, None) * np.clip(y2 - y1 + 1, 0, None)
+        return inter / ((a[2] - a[0] + 1) * (a[3] - a[1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - inter)
+    strong = found = 0
+    for c in range(80):
+        for box in ref_classes[c]:
+            if box[4] > score_min:
+                strong += 1
+                found += int(len(mine[c]) > 0 and float(iou(box, mine[c]).max()) > iou_min)
+    return strong, found
+
+
+def test_config3_r101_bf16_full_size_against_the_reference(golden_dir):
+    """BASELINE config 3 at the benchmark's size against the REFERENCE.  The
+    reference has no bf16 path (README.md:134), so the contract of the bf16 product path is
+    stated against the reference's fp32 detections of tests/golden/e2e_backbone_r101_full.npz
+    (the reference R-101 detector, 800 x 1344, its own test-time call):
+      * top-100 agreement: of the reference detections with score > 0.3, the bf16 path keeps a
+        twin (same class, IoU > 0.85) for at least as many as torch's own bf16 evaluation of the
+        plain modules (eager MIOpen bf16 convolutions + BatchNorm) does, minus 3, and for >= 55 %.
+        (Measured: 64 vs 65 of 100.  85 % -- VERDICT r3's suggestion -- is not reachable by ANY bf16
+        evaluation of this fixture: its 100 detections come out of thousands of NMS survivors with
+        near-equal scores, and 8 mantissa bits reorder the cut at max_per_img = 100.)
+      * box agreement without the rank cut: with max_per_img = 1000, >= 95 % of those reference
+        detections have a twin among the bf16 path's survivors: what bf16 changes is WHICH of the
+        near-tied survivors make the first 100, not where the boxes are;
+      * sampled head logits: RMS error relative to the RMS of the reference logits <= 2.5e-2
+        (0.6 x 2^-8 x sqrt(112 convolutions)), and <= 1.5 x eager's + 1e-3."""
+    import copy
+    from iouaware.fuse import fuse_inference
+    f = np.load(os.path.join(golden_dir, 'e2e_backbone_r101_full.npz'))
+    m = _build(dict(depth=101))
+    with torch.no_grad():
+        synth.e2e_fill_state(m.state_dict(), int(f['weight_seed']))
+    assert synth.checksum([v.numpy() for k, v in sorted(m.state_dict().items())]) == int(f['weight_checksum'])
+    m = m.cuda()
+    x, meta = _img(f, 'module')
+    want = _split(f['result_cat'], f['result_counts'])
+
+    def logits_rms(cls, reg, iou):
+        num = den = 0.0
+        for nm, ts in (('cls', cls), ('reg', reg), ('iou', iou)):
+            for lv, t in enumerate(ts):
+                a = t.float().contiguous().cpu().numpy().reshape(-1)[f['%s_idx_%d' % (nm, lv)]].astype(np.float64)
+                w = f['%s_val_%d' % (nm, lv)].astype(np.float64)
+                num += float(((a - w) ** 2).sum())
+                den += float((w ** 2).sum())
+        return (num / den) ** 0.5
+    with torch.no_grad():
+        eager = copy.deepcopy(m).to(torch.bfloat16)
+        xb = x.to(torch.bfloat16)
+        e_rms = logits_rms(*eager.forward_head(xb))
+        eager_res = eager(return_loss=False, rescale=True, img=[xb], img_meta=[[meta]])
+        del eager
+        fuse_inference(m, winograd=True)
+        mb = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
+        xc = xb.contiguous(memory_format=torch.channels_last)
+        o_rms = logits_rms(*mb.forward_head(xc))
+        res = mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]])
+        keep = mb.test_cfg.max_per_img
+        mb.test_cfg.max_per_img = 1000
+        try:
+            res_all = mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]])
+        finally:
+            mb.test_cfg.max_per_img = keep
+    strong, found = _twin_retention(want, res)
+    _, found_all = _twin_retention(want, res_all)
+    _, found_eager = _twin_retention(want, eager_res)
+    _REPORT.append('config 3 (R-101 bf16) at 800x1344 vs the reference fp32 fixture: head-logit RMS error fused %.2e, '
+                   'torch-bf16 %.2e | reference detections with score > 0.3: %d; twin (same class, IoU > 0.85) in the '
+                   'fused bf16 result: %d (%.0f %%), in torch\'s own bf16 result: %d; among the first 1000 survivors of '
+                   'the fused bf16 path: %d' % (o_rms, e_rms, strong, found, 100.0 * found / max(strong, 1),
+                                                found_eager, found_all))
+    assert o_rms <= 2.5e-2 and o_rms <= 1.5 * e_rms + 1e-3, (o_rms, e_rms)
+    assert strong >= 10
+    assert found >= 0.55 * strong and found >= found_eager - 3, (strong, found, found_eager)
+    assert found_all >= 0.95 * strong, (strong, found_all)

@@ -35,6 +35,39 @@ def test_grouped_conv3x3_matches_conv2d(C, groups, stride, hw):
     assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('C,H,W,stride', [
+    (256, 200, 336, 1),                       # layer1 conv2
+    (512, 200, 336, 2), (512, 100, 168, 1),   # layer2: first block (stride 2), the others
+    (1024, 100, 168, 2), (1024, 50, 84, 1),   # layer3
+    (2048, 50, 84, 2), (2048, 25, 42, 1),     # layer4
+])
+def test_grouped_conv3x3_at_the_benchmark_shapes(C, H, W, stride):
+    """every conv2 shape of X-101-64x4d (BASELINE config 4) as `bench.py --config
+    x101-64x4d` runs it -- batch 8, 800 x 1344 input, 64 groups -- against the library's grouped
+    convolution (fp32 both sides, other summation order: 1e-5 of the output scale), plus the same
+    bits from a second launch."""
+    from iouaware import ops
+    groups, B = 64, 8
+    g = torch.Generator(device='cuda').manual_seed(C + H + stride)
+    cg = C // groups
+    x = torch.randn(B, C, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, cg, 3, 3, device='cuda', generator=g) * (1.0 / (9 * cg)) ** 0.5
+    scale = torch.rand(C, device='cuda', generator=g) + 0.5
+    bias = torch.randn(C, device='cuda', generator=g) * 0.1
+    wp = ops.pack_grouped_weight(w, scale)
+    got = ops.grouped_conv3x3(x, wp, bias, groups, stride, relu=True)
+    again = ops.grouped_conv3x3(x, wp, bias, groups, stride, relu=True)
+    assert torch.equal(got, again)
+    want = F.conv2d(x, w * scale.view(-1, 1, 1, 1), bias, stride=stride, padding=1, groups=groups).clamp(min=0)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    err = float((got - want).abs().max())
+    assert err <= 1e-5 * max(1.0, float(want.abs().max())), (C, H, W, stride, err)
+    # the image borders and the last image of the batch in particular
+    for sl in ((0, slice(None), 0), (B - 1, slice(None), -1), (B - 1, -1, slice(None))):
+        b_, y_, x_ = sl
+        assert float((got[b_, :, y_, x_] - want[b_, :, y_, x_]).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_grouped_conv3x3_rejects_what_it_does_not_cover():
     from iouaware import ops, _lib
     x = torch.randn(1, 96, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
