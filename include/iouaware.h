@@ -155,11 +155,18 @@ int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch,
  * WORKSPACE CONTRACT of ia_get_bboxes / ia_get_bboxes_lazy / ia_decode_stage: the workspace holds a
  * few words of state (arrival counters of the fused row-max + top-k-filter launch).  Zero-fill it
  * ONCE before its first use; every call leaves it ready for the next one.  Do not let anything else
- * write to it between calls (if something did, zero it again).  ia_get_bboxes_status_offset() is the
- * byte offset of an int32 status word the launch sets when it finds the contract broken (1: a
- * filter workgroup timed out waiting, 2: counters above their maximum); 0 = fine.            */
+ * write to it between calls (if something did, zero it again; the entry points do so themselves
+ * when they fail between the fused launch and the kernel that resets the state).
+ * Bounded waits: a filter workgroup of the fused launch that gives up waiting for the row-max
+ * wavefronts (GPU shared with another process, CU masking, a debugger) records the call in the
+ * status words, and the next kernel of the same call selects from the complete row maxima instead
+ * of the candidate lists -- the detections are the same, the call is slower.
+ * ia_get_bboxes_status_offset() = byte offset of two uint32 words: [0] the id of the last call
+ * that took this fallback (0: never), [1] the number of such calls.  ia_debug_fused_spin_limit()
+ * sets the bound of the waits (tests: 0 forces the fallback; negative: the default, 2^21 polls). */
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
 size_t ia_get_bboxes_status_offset(const ia_head_geom *g, int batch);
+int ia_debug_fused_spin_limit(int64_t limit);
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                   const float *img_hw, const float *scale_factor, int rescale, float score_thr,
                   float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,

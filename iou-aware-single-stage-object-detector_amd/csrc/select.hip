@@ -31,6 +31,9 @@
 //
 // Levels with N_l <= nms_pre keep their natural order (the reference skips topk there, :537).
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 #include "ia_rowmax_dev.hpp"
@@ -68,6 +71,10 @@ struct SelArgs {
     uint64_t *cand;                        // (B, N): candidate keys; chunk c of segment (b, l) owns
                                            // [b * N + anchor_off[l] + c * kSelChunk, + kSelChunk)
     int32_t batch, anchors_per_img, cands_per_img, lds_cap, total_chunks;
+    // fused launch only (0 otherwise): the id of this call -- what a filter workgroup that gives up
+    // waiting writes into the status word, and what k_sel_final compares the word with (a stale
+    // word of an earlier call never matches: nothing has to clear it) -- and the spin bound
+    uint32_t call_id, spin_limit;
 };
 
 // The bin d (from the top) where the running count of a 2048-bin histogram reaches `need`, by a
@@ -359,7 +366,14 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
 // Residency: the filter workgroups (chunks x batch, 4 wavefronts each) can never fill the chip,
 // so a row-max workgroup always finds a slot whatever the dispatch order: no deadlock.  Spins are
 // bounded; a timeout leaves a non-zero status word in the workspace.
+// SAFETY: a workgroup that gives up waiting stores the call's id in
+// the status word and goes on (its candidate slice is then garbage, in bounds).  k_sel_final --
+// a later launch on the same stream, so every row maximum IS in memory by then -- sees the id and
+// selects from the row maxima of the whole level instead of the candidate lists: the result is the
+// same detections, only slower; status[1] counts such calls (telemetry, ops.get_bboxes_status).
 constexpr uint32_t kSpinLimit = 1u << 21;
+static uint32_t g_spin_limit = kSpinLimit;            // ia_debug_fused_spin_limit (tests)
+static std::atomic<uint32_t> g_fused_calls{0};
 
 // Four / eight L1-bypassing loads in flight per lane (agent-scope atomic loads are issued one at a
 // time, each behind a wait: a poll round of 10 words per lane took 10-20 us).
@@ -427,7 +441,7 @@ __device__ __forceinline__ uint32_t segment_threshold_polled(const SelArgs &a, c
         __syncthreads();
         present = (s_misc[8] + s_misc[9]) + (s_misc[10] + s_misc[11]);
         if (present >= need) break;
-        if (spins > kSpinLimit) { if (tid == 0) *status = 1u; break; }          // uniform
+        if (spins >= a.spin_limit) { if (tid == 0) *status = a.call_id; break; }          // uniform
         __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();                                     // s_misc[8..11] free again
@@ -457,7 +471,7 @@ __device__ __forceinline__ void chunk_ready(const SelArgs &a, const SegRef &r, u
             for (int u = 0; u < 8; ++u) ok &= (w[u] != 0u);
         }
         if (__syncthreads_and(ok)) break;
-        if (spins > kSpinLimit) { if (tid == 0) *status = 1u; break; }          // uniform
+        if (spins >= a.spin_limit) { if (tid == 0) *status = a.call_id; break; }          // uniform
         __builtin_amdgcn_s_sleep(4);
     }
 }
@@ -529,7 +543,7 @@ __global__ void __launch_bounds__(kFilterThreads, 4) k_rowmax_filter_nhwc(Rowmax
             uint32_t spins = 0;
             while (((x = __hip_atomic_load(granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > kSpinLimit) { *status = 1u; break; }
+                if (++spins > sa.spin_limit) { *status = sa.call_id; break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             s_misc[20] = (uint32_t)x;
@@ -570,8 +584,15 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
         for (uint32_t i = tid; i < n; i += nt) out[i] = (int32_t)i;
         return;
     }
-    const bool filtered = a.plan.grp[l] != 0;
-    if (filtered && a.t.layout == IA_LAYOUT_NHWC) {
+    const bool in_plan = a.plan.grp[l] != 0;
+    // a filter workgroup of THIS call timed out: its candidate slice cannot be trusted; the row
+    // maxima are complete (kernel boundary), so the level is selected from them like a dense one
+    uint32_t *status = a.chunk_count + (size_t)a.batch * a.total_chunks;
+    const bool timed_out = a.call_id != 0u && in_plan &&
+                           __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.call_id;
+    if (timed_out && l == 0 && b == 0 && tid == 0) atomicAdd(status + 1, 1u);
+    const bool filtered = in_plan && !timed_out;
+    if (in_plan && a.t.layout == IA_LAYOUT_NHWC) {
         // state of the fused launch (k_rowmax_filter_nhwc) back to zero: the segment's group words
         // -- the straddling ones too -- and its granule; nobody reads them any more in this call
         const int lg = 31 - __builtin_clz((unsigned)a.plan.grp[l]);
@@ -769,8 +790,9 @@ static SelLayout layout(const LevelTable &t, const SelPlan &p, int batch)
     const size_t B = (size_t)batch;
     size_t o = 0;
     w.seg_v = o; o = up(o + B * (size_t)t.num_levels * sizeof(uint64_t));
-    // (+1: status word of the fused launch's bounded spin)
-    w.chunk_count = o; o = up(o + (B * (size_t)p.chunk_off[IA_MAX_LEVELS] + 1) * sizeof(uint32_t));
+    // (+2: status words of the fused launch's bounded spin: id of the last call that timed out,
+    // number of calls that fell back)
+    w.chunk_count = o; o = up(o + (B * (size_t)p.chunk_off[IA_MAX_LEVELS] + 2) * sizeof(uint32_t));
     w.groupmax = o; o = up(o + (size_t)p.goff[IA_MAX_LEVELS] * sizeof(uint32_t));
     w.cand = o;
     if (p.chunk_off[IA_MAX_LEVELS] > 0)
@@ -819,6 +841,7 @@ static int prepare_select(const LevelTable &t, const float *rowmax, int batch, i
     a.anchors_per_img = t.anchor_off[t.num_levels];
     a.cands_per_img = t.cand_off[t.num_levels];
     a.total_chunks = a.plan.chunk_off[IA_MAX_LEVELS];
+    a.call_id = 0; a.spin_limit = g_spin_limit;
     // LDS of the final kernel: sel (next_pow2 of the largest k) + staged candidates
     uint32_t kmax = 1;
     for (int l = 0; l < t.num_levels; ++l) {
@@ -831,15 +854,22 @@ static int prepare_select(const LevelTable &t, const float *rowmax, int batch, i
     while (p_max < kmax) p_max <<= 1;
     a.lds_cap = kSelDenseMax;
     dyn = ((size_t)p_max + kBucketCap + (size_t)a.lds_cap) * sizeof(uint64_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        // up to 32 KiB (sel, k <= 4096) + 96 KiB (stage) + the static scratch: above the 64 KiB a
-        // kernel gets without asking
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sel_final),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((IA_MAX_NMS_PRE + kBucketCap + kSelDenseMax) * sizeof(uint64_t)));
+    // up to 32 KiB (sel, k <= 4096) + 96 KiB (stage) + the static scratch: above the 64 KiB a
+    // kernel gets without asking.  The attribute belongs to the function ON A DEVICE: set it once
+    // per device, thread-safe (a process-wide `static bool` was neither).
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((size_t)dev >= done.size()) done.resize((size_t)dev + 1, 0);
+    if (!done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_sel_final),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((IA_MAX_NMS_PRE + kBucketCap + kSelDenseMax) * sizeof(uint64_t)));
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        done[dev] = 1;
     }
     return 0;
 }
@@ -939,6 +969,9 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
     }
     const dim3 grid((unsigned)blocks), block(kFilterThreads);
     const int vpr = t.C / ppl;
+    uint32_t id = ++g_fused_calls;
+    if (id == 0u) id = ++g_fused_calls;                    // 0 = "not a fused launch"
+    a.call_id = id;
     if (dtype == IA_F32) {
         if (vpr == 20) hipLaunchKernelGGL((k_rowmax_filter_nhwc<float, 20>), grid, block, 0, s, ra, a, fo);
         else hipLaunchKernelGGL((k_rowmax_filter_nhwc<float, 0>), grid, block, 0, s, ra, a, fo);
@@ -947,10 +980,26 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
         else hipLaunchKernelGGL((k_rowmax_filter_nhwc<uint16_t, 0>), grid, block, 0, s, ra, a, fo);
     }
     rc = hip_status(hipGetLastError());
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
-                       dim3(kFinalThreads), dyn, s, a, p_max);
-    return hip_status(hipGetLastError());
+    if (!rc) {
+        hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
+                           dim3(kFinalThreads), dyn, s, a, p_max);
+        rc = hip_status(hipGetLastError());
+    }
+    if (rc) {
+        // k_sel_final did not run: the group words / granules of the fused launch may be set and
+        // would let the next call skip its waits -- back to the zero state of the contract
+        const SelPlan &pl = a.plan;
+        (void)hipMemsetAsync(workspace, 0, layout(t, pl, batch).cand, s);
+    }
+    return rc;
 }
 
 }  // namespace ia
+
+/* tests: bound of the fused launch's spins (negative: the default).  0 makes every wait give up at
+ * once, i.e. forces the fallback of k_sel_final. */
+extern "C" int ia_debug_fused_spin_limit(int64_t limit)
+{
+    ia::g_spin_limit = limit < 0 ? ia::kSpinLimit : (limit > 0xffffffffLL ? 0xffffffffu : (uint32_t)limit);
+    return 0;
+}

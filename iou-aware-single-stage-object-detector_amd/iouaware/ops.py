@@ -149,6 +149,11 @@ def level_ptrs(geom, cls, reg, iou):
 _ws_cache = {}
 
 
+def _own_workspace(device, nbytes):
+    """a workspace that one autograd node keeps from forward to backward (never shared)"""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
 def _workspace(device, nbytes):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
@@ -158,7 +163,9 @@ def _workspace(device, nbytes):
     return ws
 
 
-_state_ws_cache = {}
+import collections
+_state_ws_cache = collections.OrderedDict()
+_STATE_WS_ENTRIES = 64          # (pad shape, batch) combinations kept per process; ~7 MB per image each
 
 
 def _state_workspace(device, nbytes, layout_key):
@@ -169,17 +176,35 @@ def _state_workspace(device, nbytes, layout_key):
     key = (device.index, torch.cuda.current_stream().cuda_stream, layout_key, int(nbytes))
     ws = _state_ws_cache.get(key)
     if ws is None:
-        if len(_state_ws_cache) >= 16:
-            _state_ws_cache.clear()
+        while len(_state_ws_cache) >= _STATE_WS_ENTRIES:       # least recently used first
+            _state_ws_cache.popitem(last=False)
         ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         _state_ws_cache[key] = ws
+    else:
+        _state_ws_cache.move_to_end(key)
     return ws
 
 
 def get_bboxes_status(geom, batch, ws):
-    """status word of the last fused launch in `ws` (0 = fine): a host synchronisation, tests only"""
+    """(id of the last call whose fused launch timed out and fell back to the dense selection,
+    number of such calls) from the status words in `ws`; (0, 0) = never.  A host synchronisation:
+    telemetry and tests, not the product path (the fallback's result is correct by itself)."""
     off = _lib.lib().ia_get_bboxes_status_offset(geom.ref(), int(batch))
-    return int(ws[off:off + 4].view(torch.int32).item())
+    w = ws[off:off + 8].view(torch.int32).cpu()
+    return int(w[0]) & 0xffffffff, int(w[1]) & 0xffffffff
+
+
+def fused_spin_limit(limit=-1):
+    """bound of the fused row-max + filter launch's waits (tests: 0 forces the fallback path of
+    k_sel_final; -1 restores the default)"""
+    _lib.check(_lib.lib().ia_debug_fused_spin_limit(int(limit)), 'ia_debug_fused_spin_limit')
+
+
+def state_workspace_for(geom, cls, reg, iou):
+    """the persistent workspace `get_bboxes` uses for these head outputs (tests / telemetry)"""
+    p, B, dt, g = level_ptrs(geom, list(cls), list(reg), list(iou))
+    nbytes = _lib.lib().ia_get_bboxes_workspace_bytes(g.ref(), B)
+    return g, B, _state_workspace(cls[0].device, nbytes, (g.key, g.layout, B, dt))
 
 
 _meta_cache = {}
@@ -256,9 +281,6 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     _lib.check(rc, 'ia_get_bboxes')
     if not debug:
         return dets, labels, rows, num
-    status = get_bboxes_status(geom, B, ws)
-    if status:
-        raise _lib.IouAwareLibraryError('fused row-max / filter launch reported status %d' % status)
     off = (C.c_size_t * 8)()
     _lib.check(L.ia_get_bboxes_workspace_layout(geom.ref(), B, C.byref(off)), 'workspace_layout')
 
@@ -270,7 +292,8 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
                boxes=view(2, torch.float32, (B, geom.R, 4)),
                scores_t=view(3, torch.float32, (B, geom.C, geom.Rs)),
                keep_count=view(4, torch.int32, (B, geom.C)),
-               keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)))
+               keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)),
+               fused_fallbacks=get_bboxes_status(geom, B, ws)[1])
     return dets, labels, rows, num, dbg
 
 
@@ -1249,7 +1272,7 @@ class _HeadLossFn(torch.autograd.Function):
             raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_head_loss')
         # own buffer (not the shared inference workspace): it carries the packed targets from
         # the forward to the backward call
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _own_workspace(dev, nbytes)
         _lib.check(_lib.lib().ia_head_loss_fwd(g.ref(), C.byref(p), dt, B, C.byref(ht),
                                                C.byref(hc), _ptr(ws), nbytes, _ptr(res),
                                                _stream()), 'ia_head_loss_fwd')

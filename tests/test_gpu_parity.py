@@ -363,7 +363,7 @@ def test_fused_rowmax_filter_launch_repeated_under_load(ops, kind):
         bad += (v['cand_idx'] != idx).sum() + (v['rowmax'] != rm).sum() + (v['boxes'] != boxes).sum()
     torch.cuda.synchronize()
     assert int(bad) == 0
-    assert ops.get_bboxes_status(geom, B, st.ws) == 0
+    assert ops.get_bboxes_status(geom, B, st.ws) == (0, 0)
     assert torch.equal(v['scores_t'][:, :, :geom.R], scores_t[:, :, :geom.R])
     # the product entry point on its own state workspace, twice (the second call starts from the
     # state the first one left behind)
