@@ -39,6 +39,8 @@ extern "C" {
 
 #define IA_F32 0
 #define IA_BF16 1
+#define IA_F16 2      /* the dtype-generic operator entries only (ia_sigmoid_focal_loss_*_dt) */
+#define IA_F64 3      /* ia_sigmoid_focal_loss_*_dt, ia_nms_f64 */
 
 #define IA_LAYOUT_NCHW 0
 #define IA_LAYOUT_NHWC 1     /* needs C * sizeof(dtype) to be a multiple of 16, <= 512 bytes */
@@ -215,6 +217,14 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
 size_t ia_nms_workspace_bytes(int n);
 int ia_nms(const float *dets, int n, float iou_thr, int32_t *keep, int32_t *count, void *workspace,
            size_t workspace_bytes, void *stream);
+
+/* The same operator on DOUBLE boxes: nms_cpu_kernel<double> (nms_cpu.cpp:63 dispatches float and
+ * double; areas, intersections and the quotient in fp64, the float threshold promoted to double --
+ * the fp32 entry is not a substitute: float(1/3) as threshold suppresses an IoU of exactly 1/3 in
+ * fp32 and does not in fp64).  n <= 16384 (IA_E_LIMIT_BOXES above; csrc/nms64.hip).            */
+size_t ia_nms_f64_workspace_bytes(int n);
+int ia_nms_f64(const double *dets, int n, float iou_thr, int32_t *keep, int32_t *count,
+               void *workspace, size_t workspace_bytes, void *stream);
 
 /* mmdet.ops.nms.soft_nms (nms_wrapper.py:52-78 -> soft_nms_cpu.pyx:22-127): dets (n,5)
  * fp32 on device, n <= IA_MAX_CANDIDATES.  out_dets (n,5): surviving boxes in selection
@@ -580,6 +590,16 @@ int ia_sigmoid_focal_loss_fwd(const float *logits, const int64_t *targets, int N
 int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const float *d_losses,
                               int N, int C, float gamma, float alpha, float *d_logits,
                               void *stream);
+/* The same for every storage type the reference op is instantiated for
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF: float, double, half -- sigmoid_focal_loss_cuda.cu:128,166)
+ * plus bf16: dtype = IA_F32 / IA_F64 / IA_F16 / IA_BF16 is the type of logits, losses, d_losses and
+ * d_logits.  Like the reference kernel (expf / powf / logf) the arithmetic is single precision
+ * whatever the storage type; the result is rounded once at the store.                          */
+int ia_sigmoid_focal_loss_fwd_dt(const void *logits, int dtype, const int64_t *targets, int N, int C,
+                                 float gamma, float alpha, void *losses, void *stream);
+int ia_sigmoid_focal_loss_bwd_dt(const void *logits, int dtype, const int64_t *targets,
+                                 const void *d_losses, int N, int C, float gamma, float alpha,
+                                 void *d_logits, void *stream);
 
 /* ------------------------------------------------------------------ conv epilogues
  * In place on an NCHW tensor x (N, C, HW contiguous):

@@ -109,8 +109,7 @@ extern "C" int ia_conv1x1_stream(const float *x, const float *w, const float *bi
     const int64_t tiles = (rows + 15) / 16;
     if (tiles > 2147483647LL) return IA_E_ARG;
     a.tiles = (int32_t)tiles;
-    int64_t wgs = (tiles + 3) / 4;
-    wgs = (tiles + 7) / 8;
+    int64_t wgs = (tiles + 7) / 8;
     if (wgs > 512) wgs = 512;                              // two resident workgroups per CU, tiles strided over the wavefronts
     const dim3 grid((unsigned)wgs), block(ia::kC1Threads);
     hipStream_t s = (hipStream_t)stream;

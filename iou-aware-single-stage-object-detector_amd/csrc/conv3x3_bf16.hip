@@ -19,6 +19,9 @@
 //    neighbouring output channels of one pixel, so lane pairs swap one value (DPP) and store
 //    4 bytes each, 64-byte runs per pixel.
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 
@@ -268,7 +271,26 @@ __global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_
 }
 
 // tile shape for an H x W map: TH * TW <= max_px, patch <= max_patch, least overhang
+static void conv3_tile_shape_search(int H, int W, int max_px, int max_patch, int &TH, int &TW);
+
+// memoised per (H, W, tile size): the search walks ~3 800 shapes, twice per level and launch
 static void conv3_tile_shape(int H, int W, int max_px, int max_patch, int &TH, int &TW)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> memo;
+    const auto key = std::make_tuple(H, W, max_px, max_patch);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) { TH = it->second.first; TW = it->second.second; return; }
+    }
+    conv3_tile_shape_search(H, W, max_px, max_patch, TH, TW);
+    std::lock_guard<std::mutex> lock(mu);
+    if (memo.size() > 4096) memo.clear();
+    memo[key] = std::make_pair(TH, TW);
+}
+
+static void conv3_tile_shape_search(int H, int W, int max_px, int max_patch, int &TH, int &TW)
 {
     double best = -1.0;
     TH = 8; TW = 16;

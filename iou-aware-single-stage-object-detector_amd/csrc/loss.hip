@@ -413,14 +413,42 @@ static int launch_iou_bce(bool bwd, const ia_head_geom *g, int level, const void
 
 // ------------------------------------------------------------------ focal op (CUDA-op formula)
 struct FocalOpArgs {
-    const float *logits;
+    const void *logits;
     const int64_t *targets;
-    const float *d_losses;
-    float *out;
+    const void *d_losses;
+    void *out;
     int64_t total;
-    int32_t C;
+    int32_t C, dtype;        // IA_F32 / IA_BF16 / IA_F16 / IA_F64: storage type of logits, d_losses, out
     float gamma, alpha;
 };
+
+// the reference op is instantiated for float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// sigmoid_focal_loss_cuda.cu:128,166) and evaluates expf / powf / logf -- single precision --
+// whatever the storage type: load -> fp32 math -> one rounding at the store
+__device__ __forceinline__ float focal_op_load(const void *p, int64_t i, int dtype)
+{
+    switch (dtype) {
+    case IA_BF16: return bf16_to_f32(static_cast<const uint16_t *>(p)[i]);
+    case IA_F16: return (float)static_cast<const _Float16 *>(p)[i];
+    case IA_F64: return (float)static_cast<const double *>(p)[i];
+    default: return static_cast<const float *>(p)[i];
+    }
+}
+
+__device__ __forceinline__ void focal_op_store(void *p, int64_t i, int dtype, float v)
+{
+    switch (dtype) {
+    case IA_BF16: {
+        uint32_t u = to_bits(v);
+        u = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        static_cast<uint16_t *>(p)[i] = (uint16_t)u;
+        break;
+    }
+    case IA_F16: static_cast<_Float16 *>(p)[i] = (_Float16)v; break;
+    case IA_F64: static_cast<double *>(p)[i] = (double)v; break;
+    default: static_cast<float *>(p)[i] = v;
+    }
+}
 
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_focal_op(FocalOpArgs a)
@@ -434,7 +462,7 @@ __global__ void __launch_bounds__(256) k_focal_op(FocalOpArgs a)
         const float c1 = (t == d + 1) ? 1.0f : 0.0f;
         const float c2 = ((t >= 0) & (t != d + 1)) ? 1.0f : 0.0f;
         const float zn = 1.0f - a.alpha, zp = a.alpha;
-        const float x = a.logits[i];
+        const float x = focal_op_load(a.logits, i, a.dtype);
         const float p = 1.0f / (1.0f + expf_(-x));
         const float pm = (p > FLT_MIN_) ? p : FLT_MIN_;
         const float xs = (x >= 0.0f) ? x : 0.0f;
@@ -450,22 +478,23 @@ __global__ void __launch_bounds__(256) k_focal_op(FocalOpArgs a)
             float term2 = powf_pos_(p, a.gamma) * ((lg2 * (1.0f - p)) * a.gamma - p);
             r += -c1 * term1 * zp;
             r += -c2 * term2 * zn;
-            r = r * a.d_losses[i];
+            r = r * focal_op_load(a.d_losses, i, a.dtype);
         }
-        a.out[i] = r;
+        focal_op_store(a.out, i, a.dtype, r);
     }
 }
 
-static int launch_focal_op(bool bwd, const float *logits, const int64_t *targets,
-                           const float *d_losses, int N, int C, float gamma, float alpha,
-                           float *out, hipStream_t s)
+static int launch_focal_op(bool bwd, const void *logits, const int64_t *targets,
+                           const void *d_losses, int N, int C, float gamma, float alpha,
+                           void *out, hipStream_t s, int dtype = IA_F32)
 {
     if (N < 0 || C < 1) return IA_E_ARG;
+    if (dtype != IA_F32 && dtype != IA_BF16 && dtype != IA_F16 && dtype != IA_F64) return IA_E_ARG;
     if (N == 0) return 0;
     if (!logits || !targets || !out || (bwd && !d_losses)) return IA_E_ARG;
     FocalOpArgs a;
     a.logits = logits; a.targets = targets; a.d_losses = d_losses; a.out = out;
-    a.total = (int64_t)N * C; a.C = C; a.gamma = gamma; a.alpha = alpha;
+    a.total = (int64_t)N * C; a.C = C; a.dtype = dtype; a.gamma = gamma; a.alpha = alpha;
     int64_t blocks = (a.total + 255) / 256;
     unsigned grid = (unsigned)(blocks > 4096 ? 4096 : blocks);
     if (bwd) hipLaunchKernelGGL(k_focal_op<true>, dim3(grid), dim3(256), 0, s, a);
@@ -565,6 +594,20 @@ int ia_sigmoid_focal_loss_bwd(const float *logits, const int64_t *targets, const
 {
     return ia::launch_focal_op(true, logits, targets, d_losses, N, C, gamma, alpha, d_logits,
                                (hipStream_t)stream);
+}
+
+int ia_sigmoid_focal_loss_fwd_dt(const void *logits, int dtype, const int64_t *targets, int N, int C,
+                                 float gamma, float alpha, void *losses, void *stream)
+{
+    return ia::launch_focal_op(false, logits, targets, nullptr, N, C, gamma, alpha, losses,
+                               (hipStream_t)stream, dtype);
+}
+int ia_sigmoid_focal_loss_bwd_dt(const void *logits, int dtype, const int64_t *targets,
+                                 const void *d_losses, int N, int C, float gamma, float alpha,
+                                 void *d_logits, void *stream)
+{
+    return ia::launch_focal_op(true, logits, targets, d_losses, N, C, gamma, alpha, d_logits,
+                               (hipStream_t)stream, dtype);
 }
 
 }  // extern "C"

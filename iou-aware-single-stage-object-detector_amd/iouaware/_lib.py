@@ -12,7 +12,7 @@ IA_MAX_ANCHORS = 16
 IA_MAX_NMS_PRE = 4096
 IA_MAX_CANDIDATES = 8192
 IA_MAX_PER_IMG = 1024
-IA_F32, IA_BF16 = 0, 1
+IA_F32, IA_BF16, IA_F16, IA_F64 = 0, 1, 2, 3
 IA_LAYOUT_NCHW, IA_LAYOUT_NHWC = 0, 1
 IA_LOSS_SLOTS = 64
 IA_MAX_TARGET_BATCH = 16
@@ -110,6 +110,8 @@ SIGNATURES = {
     'ia_get_bboxes_workspace_layout': (_i, [_G, _i, C.POINTER(_sz * 8)]),
     'ia_nms_workspace_bytes': (_sz, [_i]),
     'ia_nms': (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'ia_nms_f64_workspace_bytes': (_sz, [_i]),
+    'ia_nms_f64': (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'ia_image_transform': (_i, [C.POINTER(ImageDesc), _i, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                 _i, _i, _i, _i, _vp, _vp]),
     'ia_wino_tiles': (_i, [C.POINTER(WinoGeom), C.POINTER(C.c_int32)]),
@@ -171,6 +173,8 @@ SIGNATURES = {
     'ia_grouped_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_sigmoid_focal_loss_fwd': (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_sigmoid_focal_loss_bwd': (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    'ia_sigmoid_focal_loss_fwd_dt': (_i, [_vp, _i, _vp, _i, _i, _f, _f, _vp, _vp]),
+    'ia_sigmoid_focal_loss_bwd_dt': (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     'ia_channel_affine_act': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     'ia_channel_affine_act_nhwc': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _vp]),
     'ia_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i64, _vp]),

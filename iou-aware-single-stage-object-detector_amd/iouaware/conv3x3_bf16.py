@@ -7,6 +7,8 @@ pyramid levels.  Per tower layer ONE launch covers all levels and both towers (t
 groups reading / writing the channel halves of one 2F-channel activation); bias and ReLU are the
 kernel's epilogue.  retina_reg / retina_iou (36 + 9 output channels) stay library convolutions.
 """
+import collections
+
 import torch
 
 from . import ops
@@ -19,6 +21,10 @@ class Bf16ConvHead(object):
             raise NotImplementedError('towers with norm layers / without ReLU')
         if len(convs_c) != len(convs_r) or not convs_c:
             raise NotImplementedError('towers of different depth')
+        from .fuse import _wino_ok               # plain 3x3 / stride 1 / pad 1 / dilation 1 / groups 1
+        plain = [m.conv for m in convs_c + convs_r] + [head.retina_cls]
+        if not all(_wino_ok(c) and getattr(c, 'padding_mode', 'zeros') == 'zeros' for c in plain):
+            raise NotImplementedError('the kernel covers plain 3x3 / stride-1 / pad-1 convolutions')
         F = head.feat_channels
         if head.in_channels % 32 or F % 32 or head.retina_cls.out_channels % 2:
             raise NotImplementedError('channel counts')
@@ -42,7 +48,7 @@ class Bf16ConvHead(object):
         wcls, self.b_cls = wb(head.retina_cls)
         self.w_cls = ops.conv3x3_bf16_pack(wcls)
         self.c_cls = head.retina_cls.out_channels
-        self._bufs = {}
+        self._bufs = collections.OrderedDict()
 
     def usable(self, feats):
         return (not torch.is_grad_enabled()) and all(
@@ -54,9 +60,17 @@ class Bf16ConvHead(object):
                torch.cuda.current_stream().cuda_stream)
         a = self._bufs.get(key)
         if a is None:
+            # ping-pong activations of ONE pad shape (4 names); real evaluation sees many pad shapes
+            # (keep-ratio 1333 x 800 padded to /32): keep the two most recent shapes' buffers, the
+            # caching allocator recycles the rest (the cache grew without bound, ~1.1 GB
+            # per shape at batch 16)
+            while len(self._bufs) >= 8:
+                self._bufs.popitem(last=False)
             a = self._bufs[key] = [torch.empty((x.shape[0], channels, x.shape[2], x.shape[3]),
                                                dtype=torch.bfloat16, device=x.device,
                                                memory_format=torch.channels_last) for x in feats]
+        else:
+            self._bufs.move_to_end(key)
         return a
 
     def __call__(self, feats):

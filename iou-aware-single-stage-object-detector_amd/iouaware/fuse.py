@@ -303,7 +303,7 @@ def _head_forward(self, feats):
             from .conv3x3_bf16 import Bf16ConvHead
             try:
                 c3 = Bf16ConvHead(self)
-            except NotImplementedError:
+            except (NotImplementedError, ValueError):
                 c3 = False
             self._ia_c3 = c3
         if c3 and c3.usable(feats):

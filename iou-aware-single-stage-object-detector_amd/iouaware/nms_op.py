@@ -7,28 +7,37 @@ import torch
 from . import ops
 
 
-def nms(dets, iou_thr, device_id=None):
-    """dets: (n,5) Tensor on a ROCm device, or ndarray + device_id.  Returns (dets[inds], inds)
-    in the input's type; inds ascending (the CPU reference's order, nms_cpu.cpp:58).
+def _stage(t, device_id=None):
+    """a CPU tensor on the ROCm device the kernels run on (the reference computes such inputs on
+    the host, nms_cpu.cpp; this build has no CPU compute path: it stages them to the device and
+    back, and raises when there is no device)"""
+    if t.is_cuda:
+        return t
+    if not torch.cuda.is_available():
+        raise ops._lib.IouAwareLibraryError(
+            'a CPU input needs a ROCm device to be staged to: there is no CPU compute path in this build')
+    return t.to('cuda' if device_id is None else 'cuda:{}'.format(device_id))
 
-    The reference dispatches CPU tensors to its C++ loop; this build has no CPU compute
-    path -- a CPU tensor or an ndarray without device_id raises.
-    """
+
+def nms(dets, iou_thr, device_id=None):
+    """dets: (n,5) Tensor (any device; float32 or float64, nms_cpu.cpp:63) or ndarray (with or
+    without device_id).  Returns (dets[inds], inds) in the input's type and on the input's device;
+    inds ascending (the CPU reference's order, nms_cpu.cpp:58).  CPU tensors and ndarrays -- which
+    the reference hands to its C++ loop, nms_wrapper.py:27-45 -- are staged to the ROCm device,
+    computed there and brought back."""
     if isinstance(dets, torch.Tensor):
         is_numpy, dets_th = False, dets
     elif isinstance(dets, np.ndarray):
         is_numpy = True
-        if device_id is None:
-            raise ops._lib.IouAwareLibraryError(
-                'nms on a numpy array needs device_id: there is no CPU NMS in this build')
-        dets_th = torch.from_numpy(dets).to('cuda:{}'.format(device_id))
+        dets_th = torch.from_numpy(dets)
     else:
         raise TypeError('dets must be either a Tensor or numpy array, but got {}'.format(
             type(dets)))
+    src = dets_th.device
     if dets_th.shape[0] == 0:
         inds = dets_th.new_zeros(0, dtype=torch.long)
     else:
-        inds = ops.nms_indices(dets_th, iou_thr)
+        inds = ops.nms_indices(_stage(dets_th, device_id), iou_thr).to(src)
     if is_numpy:
         inds = inds.cpu().numpy()
     return dets[inds, :], inds
@@ -73,38 +82,74 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1,
     n = multi_bboxes.shape[0]
     if n == 0:
         return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
+    src = multi_bboxes.device
+    if not multi_bboxes.is_cuda:                           # CPU inputs: staged to the device and back
+        multi_bboxes, multi_scores = _stage(multi_bboxes), _stage(multi_scores)
     cap = ops._lib.IA_MAX_PER_IMG
-    if n > ops._lib.IA_MAX_CANDIDATES:
-        raise ValueError('multiclass_nms: %d boxes, the HIP path handles at most %d per image'
-                         % (n, ops._lib.IA_MAX_CANDIDATES))
     drop_last = max_num is None or max_num < 0
+    if n > ops._lib.IA_MAX_CANDIDATES or (not drop_last and max_num > cap):
+        # beyond the batched kernels' capacities: the reference's own structure, one NMS per class
+        # (bbox_nms.py:33-56) on the single-problem entry, which takes any n
+        b, l = _multiclass_nms_per_class(multi_bboxes, multi_scores, score_thr, nms_type, cfg, max_num)
+        return b.to(src), l.to(src)
     if drop_last:
         # reference quirk (bbox_nms.py:52-56): `shape[0] > -1` is always true, so ALL survivors
         # are sorted by score (descending) and `inds[:-1]` drops the globally lowest one.
         # Emulated while the survivor count fits the library's per-image output buffer: the
         # kernel is asked for `cap` rows, which it returns unsorted (class-major) when fewer
         # survive; the sort and the drop happen below.
-        max_num = cap
-    elif max_num > cap:
-        raise ValueError('multiclass_nms: max_num=%d exceeds the per-image output capacity %d'
-                         % (max_num, cap))
+        max_num_k = cap
+    else:
+        max_num_k = int(max_num)
     Cn = multi_scores.shape[1] - 1
     Rs = (n + 63) // 64 * 64
     scores_t = multi_bboxes.new_zeros((1, Cn, Rs), dtype=torch.float32)
     scores_t[0, :, :n] = multi_scores[:, 1:].t().to(torch.float32)
     boxes = multi_bboxes.to(torch.float32).reshape(1, n, 4)
     if nms_type == 'soft_nms':
-        iou_thr = cfg.pop('iou_thr')
-        out = ops.multiclass_soft_nms(boxes, scores_t, n, score_thr, iou_thr, int(max_num), **cfg)
+        kw = dict(cfg)
+        iou_thr = kw.pop('iou_thr')
+        out = ops.multiclass_soft_nms(boxes, scores_t, n, score_thr, iou_thr, max_num_k, **kw)
     else:
-        out = ops.multiclass_nms(boxes, scores_t, n, score_thr, cfg['iou_thr'], int(max_num))
+        out = ops.multiclass_nms(boxes, scores_t, n, score_thr, cfg['iou_thr'], max_num_k)
     k = int(out[3][0].item())
     if drop_last:
         if k >= cap:
-            raise ValueError('multiclass_nms(max_num=-1): %d or more survivors, beyond the '
-                             'per-image output capacity; pass an explicit max_num' % cap)
+            # more survivors than the batched kernel's output holds: the per-class route
+            b, l = _multiclass_nms_per_class(multi_bboxes, multi_scores, score_thr, nms_type, cfg, max_num)
+            return b.to(src), l.to(src)
         dets, labels = out[0][0, :k], out[1][0, :k].to(torch.long)
         # stable: equal scores keep their concatenation order (class ascending, row ascending)
         order = torch.sort(dets[:, 4], descending=True, stable=True)[1][:max(k - 1, 0)]
-        return dets[order], labels[order]
-    return out[0][0, :k], out[1][0, :k].to(torch.long)
+        return dets[order].to(src), labels[order].to(src)
+    return out[0][0, :k].to(src), out[1][0, :k].to(torch.long).to(src)
+
+
+def _multiclass_nms_per_class(multi_bboxes, multi_scores, score_thr, nms_type, cfg, max_num):
+    """multiclass_nms as the reference writes it (bbox_nms.py:33-56): a loop over the classes,
+    one single-problem NMS each (ia_nms takes any n; soft-NMS up to IA_MAX_CANDIDATES per class),
+    class-major concatenation, then the score sort when more than max_num survive (with
+    max_num = -1: always, and the lowest survivor is dropped -- the reference's `inds[:-1]`).
+    The unbounded route behind the batched kernels' capacities."""
+    num_classes = multi_scores.shape[1]
+    bboxes, labels = [], []
+    for i in range(1, num_classes):
+        cls_inds = multi_scores[:, i] > score_thr
+        if not bool(cls_inds.any()):
+            continue
+        cls_dets = torch.cat([multi_bboxes[cls_inds, :], multi_scores[cls_inds, i, None]], dim=1)
+        if nms_type == 'soft_nms':
+            cls_dets, _ = soft_nms(cls_dets, **cfg)
+        else:
+            cls_dets, _ = nms(cls_dets, **cfg)
+        bboxes.append(cls_dets)
+        labels.append(multi_bboxes.new_full((cls_dets.shape[0],), i - 1, dtype=torch.long))
+    if not bboxes:
+        return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
+    bboxes, labels = torch.cat(bboxes), torch.cat(labels)
+    if bboxes.shape[0] > max_num:
+        # (torch.sort on CPU / device is not stable by contract; the canonical order of this build:
+        # equal scores keep their concatenation order)
+        inds = torch.sort(bboxes[:, -1], descending=True, stable=True)[1][:max_num]
+        bboxes, labels = bboxes[inds], labels[inds]
+    return bboxes, labels

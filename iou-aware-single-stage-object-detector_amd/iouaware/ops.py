@@ -293,7 +293,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
                scores_t=view(3, torch.float32, (B, geom.C, geom.Rs)),
                keep_count=view(4, torch.int32, (B, geom.C)),
                keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)),
-               fused_fallbacks=get_bboxes_status(geom, B, ws)[1])
+               fused_fallbacks=torch.tensor(get_bboxes_status(geom, B, ws)[1]))
     return dets, labels, rows, num, dbg
 
 
@@ -491,18 +491,30 @@ def soft_nms_dets(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
 
 
 def nms_indices(dets, iou_thr):
-    """Device NMS on (n,5) fp32 dets; returns ascending kept indices (int64, device)."""
+    """Device NMS on (n,5) dets; returns ascending kept indices (int64, device).  float64 dets take
+    the fp64 kernels (nms_cpu_kernel<double>, nms_cpu.cpp:63), everything else is computed in fp32
+    like the reference's float instantiation."""
     _require_gpu(dets, 'dets')
     n = dets.shape[0]
     if n == 0:
         return dets.new_zeros(0, dtype=torch.long)
-    d = dets.detach().to(torch.float32).contiguous()
     keep = torch.empty((n,), dtype=torch.int32, device=dets.device)
     cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
-    nbytes = _lib.lib().ia_nms_workspace_bytes(n)
-    ws = _workspace(dets.device, nbytes)
-    _lib.check(_lib.lib().ia_nms(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _ptr(ws),
-                                 nbytes, _stream()), 'ia_nms')
+    L = _lib.lib()
+    if dets.dtype == torch.float64:
+        d = dets.detach().contiguous()
+        nbytes = L.ia_nms_f64_workspace_bytes(n)
+        if nbytes == 0:
+            raise _lib.IouAwareLibraryError('nms on float64 boxes handles at most 16384 boxes, got %d' % n)
+        ws = _workspace(dets.device, nbytes)
+        _lib.check(L.ia_nms_f64(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _ptr(ws), nbytes,
+                                _stream()), 'ia_nms_f64')
+    else:
+        d = dets.detach().to(torch.float32).contiguous()
+        nbytes = L.ia_nms_workspace_bytes(n)
+        ws = _workspace(dets.device, nbytes)
+        _lib.check(L.ia_nms(_ptr(d), n, float(iou_thr), _ptr(keep), _ptr(cnt), _ptr(ws), nbytes,
+                            _stream()), 'ia_nms')
     m = int(cnt.item())
     return keep[:m].to(torch.long)
 
@@ -1476,34 +1488,43 @@ def head_loss(geom, cls, reg, iou, labels, label_weights, bbox_targets, bbox_wei
     return out
 
 
+_FOCAL_OP_DTYPES = {torch.float32: _lib.IA_F32, torch.bfloat16: _lib.IA_BF16, torch.float16: _lib.IA_F16,
+                    torch.float64: _lib.IA_F64}
+
+
 class _SigmoidFocalLossOpFn(torch.autograd.Function):
-    """the reference's mmdet.ops.sigmoid_focal_loss op (integer targets, no weights)."""
+    """the reference's mmdet.ops.sigmoid_focal_loss op (integer targets, no weights) in the
+    logits' own storage type -- float, double, half like the reference's dispatch
+    (sigmoid_focal_loss_cuda.cu:128,166), plus bf16: no fp32 copies around the kernel."""
 
     @staticmethod
     def forward(ctx, logits, targets, gamma, alpha):
         _require_gpu(logits, 'input')
         if logits.dim() != 2:
             raise RuntimeError('logits should be NxClass')
-        x = logits.contiguous().to(torch.float32)
+        if logits.dtype not in _FOCAL_OP_DTYPES:
+            raise TypeError('sigmoid_focal_loss: floating-point logits expected, got %s' % logits.dtype)
+        x = logits.contiguous()
         t = targets.contiguous().to(torch.int64)
+        dt = _FOCAL_OP_DTYPES[x.dtype]
         out = torch.empty_like(x)
-        _lib.check(_lib.lib().ia_sigmoid_focal_loss_fwd(_ptr(x), _ptr(t), x.shape[0], x.shape[1],
-                                                        float(gamma), float(alpha), _ptr(out),
-                                                        _stream()), 'ia_sigmoid_focal_loss_fwd')
+        _lib.check(_lib.lib().ia_sigmoid_focal_loss_fwd_dt(_ptr(x), dt, _ptr(t), x.shape[0], x.shape[1],
+                                                           float(gamma), float(alpha), _ptr(out),
+                                                           _stream()), 'ia_sigmoid_focal_loss_fwd_dt')
         ctx.save_for_backward(x, t)
-        ctx.cfg = (float(gamma), float(alpha), logits.dtype)
-        return out.to(logits.dtype)
+        ctx.cfg = (float(gamma), float(alpha), dt)
+        return out
 
     @staticmethod
     def backward(ctx, d_loss):
         x, t = ctx.saved_tensors
         gamma, alpha, dt = ctx.cfg
-        d = d_loss.contiguous().to(torch.float32)
+        d = d_loss.contiguous().to(x.dtype)
         out = torch.empty_like(x)
-        _lib.check(_lib.lib().ia_sigmoid_focal_loss_bwd(_ptr(x), _ptr(t), _ptr(d), x.shape[0],
-                                                        x.shape[1], gamma, alpha, _ptr(out),
-                                                        _stream()), 'ia_sigmoid_focal_loss_bwd')
-        return out.to(dt), None, None, None
+        _lib.check(_lib.lib().ia_sigmoid_focal_loss_bwd_dt(_ptr(x), dt, _ptr(t), _ptr(d), x.shape[0],
+                                                           x.shape[1], gamma, alpha, _ptr(out),
+                                                           _stream()), 'ia_sigmoid_focal_loss_bwd_dt')
+        return out, None, None, None
 
 
 def sigmoid_focal_loss_elementwise(logits, targets, gamma=2.0, alpha=0.25):

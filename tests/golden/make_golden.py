@@ -114,6 +114,37 @@ def gen_nms():
     save('nms', **out)
 
 
+def gen_nms_f64():
+    """nms_cpu_kernel<double> (nms_cpu.cpp:63 dispatches float AND double): the reference's own
+    compiled op on float64 boxes -- random sets, and the cases where the type decides: an IoU of
+    exactly 1/3 against the threshold float(1/3) (fp32: suppressed, fp64: kept), coordinates that
+    differ below fp32 resolution."""
+    rs = np.random.RandomState(12)
+    out = {}
+    cases = [(1, 0.5), (2, 0.5), (65, 0.3), (200, 0.5), (1000, 0.7), (4693, 0.5), (9000, 0.6)]
+    for i, (n, thr) in enumerate(cases):
+        dets = rand_dets(rs, n, span=300.0 if n < 3000 else 900.0).astype(np.float64)
+        dets[:, :4] += rs.uniform(-1e-9, 1e-9, (n, 4))               # below fp32 resolution
+        dets[:, 4] = rs.permutation(n).astype(np.float64) / max(n, 1) * 0.9 + 0.05 + rs.uniform(0, 1e-12, n)
+        _, inds = nw.nms(torch.from_numpy(dets), thr)
+        assert inds.dtype == torch.int64
+        out['dets_%d' % i] = dets
+        out['thr_%d' % i] = np.float32(thr)
+        out['keep_%d' % i] = inds.numpy()
+    d = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float64)   # inter 50, union 150: IoU = 1/3
+    for j, thr in enumerate((1.0 / 3.0, 0.34, 0.33)):
+        for dt in (np.float64, np.float32):
+            _, inds = nw.nms(torch.from_numpy(d.astype(dt)), float(np.float32(thr)))
+            out['edge_keep_%d_%s' % (j, np.dtype(dt).name)] = inds.numpy()
+        out['edge_thr_%d' % j] = np.float32(thr)
+    out['edge_dets'] = d
+    assert out['edge_keep_0_float64'].tolist() == [0, 1] and out['edge_keep_0_float32'].tolist() == [0]
+    out['num_cases'] = len(cases)
+    print('nms_f64: kept', [len(out['keep_%d' % i]) for i in range(len(cases))],
+          'edge', {k: v.tolist() for k, v in out.items() if k.startswith('edge_keep')})
+    save('nms_f64', **out)
+
+
 # ---------------------------------------------------------------- get_bboxes (I5..I9)
 class Capture(object):
     """record what the reference computes inside get_bboxes_single"""
@@ -417,6 +448,25 @@ def gen_mnms_quirk():
         print('mnms', name, b.shape, 'labels of the first 5', l[:5].tolist())
     assert out['bboxes_m1'].shape[0] == out['bboxes_all'].shape[0] - 1
     save('mnms_quirk', **out)
+
+
+def gen_mnms_big():
+    """multiclass_nms beyond the batched kernels' capacities (bbox_nms.py:33-56 takes any n and
+    any max_num): 12 000 boxes, 3 classes, thousands of survivors; max_num = -1 (the quirk), 3 000
+    and 100.  Inputs are regenerated from the seed (tests/synth-style RandomState recipe below);
+    the fixture stores the outputs and a checksum of the inputs."""
+    from mmdet.core.post_processing.bbox_nms import multiclass_nms
+    boxes, sc = synth.mnms_big_inputs()
+    out = dict(seed=23, n=boxes.shape[0], checksum=synth.checksum([boxes, sc]),
+               score_thr=np.float32(0.2), iou_thr=np.float32(0.5))
+    cfg = dict(type='nms', iou_thr=0.5)
+    for name, mx in (('m1', -1), ('k3000', 3000), ('k100', 100)):
+        b, l = multiclass_nms(torch.from_numpy(boxes), torch.from_numpy(sc), 0.2, cfg, mx)
+        out['bboxes_' + name] = b.numpy()
+        out['labels_' + name] = l.numpy().astype(np.int16)
+        print('mnms_big', name, b.shape)
+    assert out['bboxes_m1'].shape[0] > 1024
+    save('mnms_big', **out)
 
 
 # ---------------------------------------------------------------- get_bboxes, 4-vector scale_factor
@@ -873,7 +923,7 @@ def gen_model():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones', 'mnms_quirk', 'get_bboxes_vecscale',
+    which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones', 'mnms_quirk', 'get_bboxes_vecscale', 'nms_f64', 'mnms_big',
                              'losses_mixed_pad']
     for w in which:
         if ':' in w:                          # e.g. e2e_backbones:r101_full,x101_64x4d_full

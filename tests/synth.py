@@ -153,3 +153,17 @@ def e2e_gts(seed, img_h, img_w):
     """gt boxes / labels for the test-time call (dead inputs in the reference, :517-524)."""
     g, l = train_targets(seed, 1, img_h, img_w, max_gt=4)
     return g[0], l[0]
+
+
+def mnms_big_inputs(seed=23, n=12000):
+    """boxes (n, 4) and scores (n, 4: background + 3 classes) of tests/golden/mnms_big.npz:
+    more boxes than one batched launch holds, thousands of NMS survivors, tie-free scores"""
+    rs = np.random.RandomState(seed)
+    xy = rs.uniform(0, 3000, (n, 2))
+    boxes = np.concatenate([xy, xy + rs.uniform(8, 60, (n, 2))], 1).astype(np.float32)
+    sc = np.zeros((n, 4), np.float32)
+    perm = [rs.permutation(3 * n)[:n] for _ in range(3)]
+    for c in range(3):
+        sc[:, c + 1] = ((perm[c].astype(np.float64) * 3 + c + 0.5) / (9.0 * n + 3)).astype(np.float32)
+    assert np.unique(sc[:, 1:]).size == 3 * n
+    return boxes, sc

@@ -7,6 +7,8 @@ import glob
 import json
 import os
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn as nn
@@ -126,8 +128,21 @@ def test_get_bboxes_refuses_cpu_tensors():
         m.bbox_head.get_bboxes(*outs, None, None, meta, m.test_cfg, True)
 
 
-def test_nms_ops_reject_like_the_reference():
-    from iouaware import nms_op
+def test_nms_ops_accept_and_reject_like_the_reference():
+    """type errors like the reference's; CPU tensors / ndarrays are ACCEPTED like the reference's
+    (nms_wrapper.py:27-45) -- staged to the ROCm device (tests/test_gpu_native_ops.py); on a host
+    without a device they fail loudly: there is no CPU compute path in this build"""
+    from iouaware import nms_op, _lib
+    if not torch.cuda.is_available():
+        for call in (lambda: nms_op.nms(torch.zeros(3, 5), 0.5),
+                     lambda: nms_op.nms(np.zeros((3, 5), np.float32), 0.5),
+                     lambda: nms_op.multiclass_nms(torch.zeros(3, 4), torch.ones(3, 3), 0.05,
+                                                   dict(type='nms', iou_thr=0.5))):
+            with pytest.raises(_lib.IouAwareLibraryError, match='no CPU compute path'):
+                call()
+    # empty inputs never reach a kernel (nms_wrapper.py:38-39, bbox_nms.py:58-60)
+    d, i = nms_op.nms(torch.zeros(0, 5), 0.5)
+    assert d.shape == (0, 5) and i.dtype == torch.long and i.numel() == 0
     with pytest.raises(ValueError):                       # nms_wrapper.py:66
         nms_op.soft_nms(torch.zeros(1, 5), 0.5, method='quadratic')
     with pytest.raises(TypeError):                        # nms_wrapper.py:59-62
@@ -200,16 +215,19 @@ def test_checkpoint_loads_with_the_safe_unpickler_by_default(tmp_path):
     assert checkpoint.load_checkpoint(m, bad, allow_pickle=True)['meta']['obj'] is not None
 
 
-def test_multiclass_nms_wrapper_validates_its_limits():
-    """explicit errors instead of the C ABI's generic 'argument error'"""
+def test_multiclass_nms_wrapper_has_no_capacity_errors_left():
+    """round 1-3 raised ValueError above IA_MAX_CANDIDATES boxes / IA_MAX_PER_IMG outputs; the
+    reference takes any n and any max_num (bbox_nms.py:33-56), and so does the wrapper now (the
+    per-class route, tests/test_gpu_native_ops.py).  What is left without a device: the loud
+    failure of a build without a CPU compute path."""
     from iouaware import nms_op, _lib
     cfg = dict(type='nms', iou_thr=0.5)
-    with pytest.raises(ValueError, match='at most'):
-        nms_op.multiclass_nms(torch.zeros(_lib.IA_MAX_CANDIDATES + 1, 4),
-                              torch.zeros(_lib.IA_MAX_CANDIDATES + 1, 3), 0.05, cfg, 100)
-    with pytest.raises(ValueError, match='max_num'):
-        nms_op.multiclass_nms(torch.zeros(8, 4), torch.zeros(8, 3), 0.05, cfg,
-                              _lib.IA_MAX_PER_IMG + 1)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.IouAwareLibraryError, match='no CPU compute path'):
+            nms_op.multiclass_nms(torch.zeros(_lib.IA_MAX_CANDIDATES + 1, 4),
+                                  torch.ones(_lib.IA_MAX_CANDIDATES + 1, 3), 0.05, cfg, 100)
+    with pytest.raises(NotImplementedError):              # class-specific boxes: two-stage feature
+        nms_op.multiclass_nms(torch.zeros(8, 12), torch.zeros(8, 4), 0.05, cfg, 10)
 
 
 @pytest.mark.parametrize('name,backbone', [
