@@ -62,13 +62,23 @@ struct SelPlan {
     int32_t chunk_off[IA_MAX_LEVELS + 1];// prefix of ceil(N_l / kSelChunk) over filtered levels
 };
 
-// group arrays: channels-last heads: groups of g consecutive rows of the flat (B * N_l) row space
-// of a level (row = b * N_l + reference anchor index); NCHW heads: per (image, anchor) plane,
-// groups of g consecutive positions (the row-max array is stored anchor-major there)
-inline int64_t sel_group_count(const LevelTable &t, int l, int g, int batch)
+// group arrays: channels-last heads: PER IMAGE, groups of g consecutive reference anchor indices
+// (ceil(N_l / g) words per image: no group, and no 64-row unit of the row-max wavefronts,
+// straddles two images -- the state of a segment (image, level) can then be reset by that segment's
+// own consumers); NCHW heads: per (image, anchor) plane, groups of g consecutive positions (the
+// row-max array is stored anchor-major there)
+inline int64_t sel_groups_per_image(const LevelTable &t, int l, int g)
 {
     const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
-    if (t.layout == IA_LAYOUT_NHWC) return ((int64_t)batch * n + g - 1) / g;
+    return (n + g - 1) / g;
+}
+inline int64_t sel_units_per_image(const LevelTable &t, int l)      // 64-row units of the row-max wavefronts
+{
+    return ((int64_t)(t.anchor_off[l + 1] - t.anchor_off[l]) + 63) / 64;
+}
+inline int64_t sel_group_count(const LevelTable &t, int l, int g, int batch)
+{
+    if (t.layout == IA_LAYOUT_NHWC) return (int64_t)batch * sel_groups_per_image(t, l, g);
     const int64_t hw = (int64_t)t.H[l] * t.W[l];
     return (int64_t)batch * t.A * ((hw + g - 1) / g);
 }

@@ -86,21 +86,23 @@ __device__ __forceinline__ void store_wt_b32(float *p, float v)
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One wavefront: 64 consecutive rows (unit `rem` of level `l`).
+// One wavefront: 64 consecutive rows of ONE image (unit `rem` of level `l`; ceil(N_l / 64) units
+// per image, the last one partial).
 //   PUBLISH = false: plain stores (the next kernel reads them);
 //   PUBLISH = true : the scores go out as write-through stores, the wavefront drains its memory
 //                    counter, and only then stores the group maxima of its rows -- non-zero words
 //                    (ordered keys) that are the "these 64 rows are in memory" flags the filter
 //                    workgroups of the same launch wait for (Guideline 16 R1: payload, drain, flag).
-template <typename T, int VPR_T, bool PUBLISH>         // VPR_T = 0: run-time vectors per row
-__device__ __forceinline__ void rowmax_nhwc_wave(const RowmaxNhwcArgs &a, int l, int rem, float *s_m, int lane)
+template <typename T, int VPR_T, bool PUBLISH, typename AT = RowmaxNhwcArgs>   // VPR_T = 0: run-time vectors per row
+__device__ __forceinline__ void rowmax_nhwc_wave(const AT &a, int l, int rem, float *s_m, int lane)
 {
     constexpr int PPL = Lane<T>::PPL;
     const int vpr = VPR_T ? VPR_T : a.t.C / PPL;
     const int n_l = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
-    const int64_t rows = (int64_t)a.batch * n_l;
-    const int64_t r0 = (int64_t)rem * 64;
-    const int nrow = (rows - r0 < 64) ? (int)(rows - r0) : 64;
+    const int upi = (n_l + 63) >> 6;                       // units per image
+    const int b = rem / upi, u0 = (rem - b * upi) * 64;    // image, first anchor index of the unit
+    const int64_t r0 = (int64_t)b * n_l + u0;              // row of the level's flat (B * N_l) space
+    const int nrow = (n_l - u0 < 64) ? (n_l - u0) : 64;
     const int nvec = nrow * vpr;
     const T *src = static_cast<const T *>(a.p.cls[l]) + r0 * a.t.C;
     // this lane's row: its IoU logit is requested first so that its latency hides behind the
@@ -143,7 +145,6 @@ __device__ __forceinline__ void rowmax_nhwc_wave(const RowmaxNhwcArgs &a, int l,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float score = 0.0f;                                     // scores are >= 0
-    const int b = (int)(g / n_l);
     const int i = (int)(g - (int64_t)b * n_l);
     float *dst = a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i;
     if (lane < nrow) {
@@ -166,10 +167,9 @@ __device__ __forceinline__ void rowmax_nhwc_wave(const RowmaxNhwcArgs &a, int l,
         const int q = lane & ~3;
         ia_f32x4 v4;
         v4.x = __shfl(score, q); v4.y = __shfl(score, q + 1); v4.z = __shfl(score, q + 2); v4.w = __shfl(score, q + 3);
-        const int b3 = __shfl(b, q + 3), b0 = __shfl(b, q);
-        const bool quad = (q + 3 < nrow) && (b0 == b3);
-        const bool aligned = quad && ((reinterpret_cast<uintptr_t>(a.rowmax + (size_t)b0 * a.anchors_per_img + a.t.anchor_off[l] +
-                                                                    (size_t)(g - (lane - q) - (int64_t)b0 * n_l)) & 15u) == 0);
+        const bool quad = q + 3 < nrow;                      // (a unit lies inside one image)
+        const bool aligned = quad && ((reinterpret_cast<uintptr_t>(a.rowmax + (size_t)b * a.anchors_per_img + a.t.anchor_off[l] +
+                                                                    (size_t)(u0 + q)) & 15u) == 0);
 #ifdef IA_ABL_PLAIN_STORE                                    /* tools/ubench/stage_bench.hip only */
         if (lane < nrow) *dst = score;
 #else
@@ -181,14 +181,13 @@ __device__ __forceinline__ void rowmax_nhwc_wave(const RowmaxNhwcArgs &a, int l,
 #endif
     }
     if (a.groupmax && grp) {
-        // maxima of groups of grp consecutive rows of this level's flat (B * N_l) row space, as
-        // ordered keys (score bits | sign bit: scores are >= +0, so the word is never 0); r0 is a
-        // multiple of 64, so the groups are lane-aligned (a group that straddles two images is
-        // written like any other and left out of the threshold by the reader)
+        // maxima of groups of grp consecutive anchors of this image, as ordered keys (score bits |
+        // sign bit: scores are >= +0, so the word is never 0); u0 is a multiple of 64, so the
+        // groups are lane-aligned; ceil(N_l / grp) words per image
         const uint32_t key = __builtin_bit_cast(uint32_t, lanes_max(score, grp)) | 0x80000000u;
         if (pub) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // scores are in memory
         if ((lane & (grp - 1)) == 0 && lane < nrow) {
-            uint32_t *gp = a.groupmax + a.plan.goff[l] + (r0 + lane) / grp;
+            uint32_t *gp = a.groupmax + a.plan.goff[l] + (size_t)b * ((n_l + grp - 1) / grp) + (u0 + lane) / grp;
             if (pub) __hip_atomic_store(gp, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *gp = key;
         }

@@ -126,7 +126,8 @@ __device__ __forceinline__ int bin_shift(uint32_t range)
 
 struct SegRef { int l, b; uint32_t n, k, beg, cnt, chunk; const float *src; bool natural; uint32_t HW, A; };
 
-__device__ __forceinline__ SegRef locate_chunk(const SelArgs &a, int cx, int b)
+template <typename AT>
+__device__ __forceinline__ SegRef locate_chunk(const AT &a, int cx, int b)
 {
     SegRef r;
     r.b = b;
@@ -152,9 +153,8 @@ __device__ __forceinline__ void segment_groups(const LevelTable &t, int l, int b
     const int lg = 31 - __builtin_clz((unsigned)g);
     const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
     if (t.layout == IA_LAYOUT_NHWC) {
-        first = ((int64_t)b * n + g - 1) >> lg;
-        const int64_t end = ((int64_t)(b + 1) * n) >> lg;
-        count = end > first ? end - first : 0;
+        count = (n + g - 1) >> lg;                       // per-image group words (the last one may be partial)
+        first = (int64_t)b * count;
     } else {
         const int64_t gpp = ((int64_t)t.H[l] * t.W[l] + g - 1) >> lg;
         first = (int64_t)b * t.A * gpp;
@@ -175,10 +175,11 @@ __global__ void __launch_bounds__(256) k_sel_groupmax(SelArgs a, uint32_t *group
     const int64_t n = a.t.anchor_off[l + 1] - a.t.anchor_off[l];
     float m = 0.0f;                                 // scores are >= 0
     if (a.t.layout == IA_LAYOUT_NHWC) {
+        const int64_t gpi = (n + g - 1) / g;             // group words per image
+        const int64_t b = gid / gpi, q = gid - b * gpi;
         for (int j = 0; j < g; ++j) {
-            const int64_t r = gid * g + j;
-            if (r >= (int64_t)a.batch * n) break;
-            const int64_t b = r / n, i = r - b * n;
+            const int64_t i = q * g + j;
+            if (i >= n) break;
             const float v = a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i];
             m = (m < v) ? v : m;
         }
@@ -244,7 +245,8 @@ __device__ __forceinline__ uint32_t threshold_from_keys(const uint32_t (&gk)[kGr
 // v: a lower bound of segment r's k-th largest key from (a sample of) its group maxima -- ONE
 // histogram pass over 2048 linear bins between their minimum and maximum, v = the lower edge of the
 // bin where the count from the top reaches k.  s_hist must be zero on entry (and a barrier later).
-__device__ __forceinline__ uint32_t segment_threshold(const SelArgs &a, const SegRef &r, uint32_t *s_hist,
+template <typename AT>
+__device__ __forceinline__ uint32_t segment_threshold(const AT &a, const SegRef &r, uint32_t *s_hist,
                                                       uint32_t *s_misc)
 {
     const int tid = threadIdx.x;
@@ -269,7 +271,8 @@ __device__ __forceinline__ uint32_t segment_threshold(const SelArgs &a, const Se
 
 // One filter workgroup: the scores >= v of its chunk -> the chunk's slice of the candidate list.
 // have_v: the threshold is given (a follower of the fused launch); else derived here.
-__device__ __forceinline__ void sel_filter_body(const SelArgs &a, const SegRef &r, uint32_t *s_hist,
+template <typename AT>
+__device__ __forceinline__ void sel_filter_body(const AT &a, const SegRef &r, uint32_t *s_hist,
                                                 uint32_t *s_misc /* 24 words */, bool have_v = false,
                                                 uint32_t v_given = 0)
 {
@@ -397,7 +400,8 @@ __device__ __forceinline__ void load8_sc1(const uint32_t *const (&q)[8], uint32_
 // an eighth of them are published, and derives v from the keys it then holds -- no second read,
 // and the threshold is out long before the segment's last row-max wavefront finishes (what a
 // follower waits for is its OWN chunk, chunk_ready below).  s_hist zero on entry.
-__device__ __forceinline__ uint32_t segment_threshold_polled(const SelArgs &a, const SegRef &r, uint32_t *s_hist,
+template <typename AT>
+__device__ __forceinline__ uint32_t segment_threshold_polled(const AT &a, const SegRef &r, uint32_t *s_hist,
                                                              uint32_t *s_misc, uint32_t *status)
 {
     const int tid = threadIdx.x;
@@ -449,12 +453,13 @@ __device__ __forceinline__ uint32_t segment_threshold_polled(const SelArgs &a, c
 }
 
 // every row of chunk r is in memory: the group words that cover it are published
-__device__ __forceinline__ void chunk_ready(const SelArgs &a, const SegRef &r, uint32_t *status)
+template <typename AT>
+__device__ __forceinline__ void chunk_ready(const AT &a, const SegRef &r, uint32_t *status)
 {
     const int tid = threadIdx.x;
     const int lg = 31 - __builtin_clz((unsigned)a.plan.grp[r.l]);
-    const int64_t row0 = (int64_t)r.b * r.n + r.beg;
-    const int64_t w0 = row0 >> lg, w1 = ((row0 + r.cnt - 1) >> lg) + 1;
+    const int64_t gpi = ((int64_t)r.n + a.plan.grp[r.l] - 1) >> lg;     // group words per image
+    const int64_t w0 = (int64_t)r.b * gpi + (r.beg >> lg), w1 = (int64_t)r.b * gpi + ((r.beg + r.cnt - 1) >> lg) + 1;
     const uint32_t *gw = a.groupmax + a.plan.goff[r.l];
     for (uint32_t spins = 0;; ++spins) {
         int ok = 1;
@@ -596,7 +601,8 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
         // state of the fused launch (k_rowmax_filter_nhwc) back to zero: the segment's group words
         // -- the straddling ones too -- and its granule; nobody reads them any more in this call
         const int lg = 31 - __builtin_clz((unsigned)a.plan.grp[l]);
-        const int64_t g0 = ((int64_t)b * n) >> lg, g1 = (((int64_t)(b + 1) * n - 1) >> lg) + 1;
+        const int64_t gpi = ((int64_t)n + a.plan.grp[l] - 1) >> lg;
+        const int64_t g0 = (int64_t)b * gpi, g1 = g0 + gpi;
         uint32_t *gw = const_cast<uint32_t *>(a.groupmax) + a.plan.goff[l];
         for (int64_t j = g0 + tid; j < g1; j += nt) gw[j] = 0u;
         if (tid == 0) a.seg_v[(size_t)b * a.t.num_levels + l] = 0ull;
@@ -948,7 +954,7 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
         auto chunks = [&](int l) { return (int64_t)(a.plan.chunk_off[l + 1] - a.plan.chunk_off[l]); };
         for (int l = 0; l < IA_MAX_LEVELS; ++l) fo.units[l] = 0;
         for (int l = 0; l < t.num_levels; ++l) {
-            const int64_t units = ((int64_t)batch * (t.anchor_off[l + 1] - t.anchor_off[l]) + 63) / 64;
+            const int64_t units = (int64_t)batch * sel_units_per_image(t, l);
             if (units > 2147483647LL) return IA_E_ARG;
             fo.units[l] = (int32_t)units;
             if ((rc = push(l, 0, (units + 3) / 4))) return rc;
