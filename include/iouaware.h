@@ -338,6 +338,12 @@ int ia_linear_bias_act_bf16(const void *A, const void *W, const float *bias, con
  * b < batch, contiguous row-major stacks; same library, same per-shape candidate timing.      */
 int ia_batched_gemm(const float *A, const float *W, float *D, int batch, int64_t rows, int k, int n,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* The same product for the HBM-bound shapes -- (k, n) in {(64, 64), (128, 128), (256, 48)}: the
+ * Winograd-domain GEMMs of the 64- / 128-channel bottleneck convolutions and of the reg | iou
+ * output -- on this library's streaming MFMA kernel (csrc/conv1x1_stream.hip: one grid row per
+ * matrix, its weights in LDS); no workspace.                                                    */
+int ia_batched_gemm_stream(const float *A, const float *W, float *D, int batch, int64_t rows, int k,
+                           int n, void *stream);
 
 /* Convolutions with a stride as plain contractions with a FIXED reduction order (the library
  * convolution's fast fp32 channels-last kernels for these shapes split the reduction and add the
@@ -644,6 +650,13 @@ int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, 
  * (+ residual)), fp32, x (rows, k), w (k, n) row-major, (k, n) in {(64, 256), (256, 64), (64, 64)}. */
 int ia_conv1x1_stream(const float *x, const float *w, const float *bias, const float *residual,
                       float *y, int64_t rows, int k, int n, int relu, void *stream);
+/* The boundary between two stage-1 bottlenecks in one pass (resnet.py:215-255: conv3 + bn3 + add +
+ * ReLU of a block, then conv1 + bn1 + ReLU of the next): y = relu(x . w + bias + residual) (rows, n)
+ * is stored and, from the accumulators, h = relu(y . w2 + bias2) (rows, n2) -- the second product
+ * does not read y back.  fp32, (k, n, n2) = (64, 256, 64), residual / biases may be NULL.      */
+int ia_conv1x1_chain(const float *x, const float *w, const float *bias, const float *residual,
+                     const float *w2, const float *bias2, float *y, float *h, int64_t rows, int k,
+                     int n, int n2, void *stream);
 
 /* ------------------------------------------------------------------ bf16 3x3 convolution
  * 3x3 / stride 1 / pad 1 convolution + bias (+ReLU) on bf16 channels-last tensors, fp32

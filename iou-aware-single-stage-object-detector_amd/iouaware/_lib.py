@@ -131,6 +131,7 @@ SIGNATURES = {
     'ia_linear_bias_act': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_linear_bias_act_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_batched_gemm': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    'ia_batched_gemm_stream': (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     'ia_linear_bias_act_wt': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
     'ia_gemm_tuning': (_i, [_i]),
     'ia_im2col3x3_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -180,6 +181,7 @@ SIGNATURES = {
     'ia_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i64, _vp]),
     'ia_upsample2x_add_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_conv1x1_stream': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp]),
+    'ia_conv1x1_chain': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'ia_conv3x3_bf16_packed_bytes': (C.c_size_t, [_i, _i, _i]),
     'ia_conv3x3_bf16_pack': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'ia_conv3x3_bf16_levels': (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -103,14 +103,24 @@ def _train(module):
 
 
 def _bottleneck_forward(self, x):
+    return _bottleneck_run(self, x)[0]
+
+
+def _bottleneck_run(self, x, h1=None, nxt=None):
+    """-> (y, h).  h1: this block's conv1 + bn1 + ReLU output, already computed by the block in
+    front (chained stage-1 boundary, ops.conv1x1_chain); nxt: the next block's folded copies -- the
+    tail then produces y AND the next block's h1 in one kernel (h is None when it did not).  Both
+    only from _layer_forward, which has checked the shapes."""
     if not _fast(self, x):
         if _train(self) and train_fuse.bottleneck_usable(self, x):
-            return train_fuse.bottleneck_forward(self, x)      # training, eval-mode BatchNorm
-        return type(self).forward(self, x)
+            return train_fuse.bottleneck_forward(self, x), None      # training, eval-mode BatchNorm
+        return type(self).forward(self, x), None
     f = self._ia_fused
     lt = 'w1' in f and x.dtype in (torch.float32, torch.bfloat16) \
         and x.is_contiguous(memory_format=torch.channels_last)
-    if lt:
+    if h1 is not None:
+        w, out, pre = f, h1, None
+    elif lt:
         # 1x1 convolutions = library GEMMs on the channels-last activation, folded BN / residual /
         # ReLU in the GEMM epilogue (csrc/gemm.hip); bf16 networks use bf16 copies of the folded
         # weights (biases stay fp32, accumulation is fp32)
@@ -141,22 +151,57 @@ def _bottleneck_forward(self, x):
         out = ops.channel_affine_act_(self.conv2(out), f['s2'], f['b2'], relu=True)
     if lt and out.is_contiguous(memory_format=torch.channels_last):
         if self.downsample is None:
-            return ops.linear_bias_act(out, w['w3'], f['b3'], residual=x, relu=True)
+            if nxt is not None:
+                return ops.conv1x1_chain(out, w['w3'], f['b3'], x, nxt['w1'], nxt['b1'])
+            return ops.linear_bias_act(out, w['w3'], f['b3'], residual=x, relu=True), None
         if 'wd' in f:                     # stride-1 projection: a GEMM as well
             idn = ops.linear_bias_act(x, w['wd'], f['b3d'])
-            return ops.linear_bias_act(out, w['w3'], None, residual=idn, relu=True)
+            if nxt is not None:
+                return ops.conv1x1_chain(out, w['w3'], None, idn, nxt['w1'], nxt['b1'])
+            return ops.linear_bias_act(out, w['w3'], None, residual=idn, relu=True), None
         ds = self.downsample[0]
         if 'wd_s' in f:                   # strided projection: one strided-batched GEMM, input read in place
             idn = ops.conv1x1_strided(x, w['wd_s'], None, None, stride=ds.stride[0])
         else:
             idn = F.conv2d(x, w['wd_conv'], None, ds.stride, ds.padding)
-        return ops.linear_bias_act(out, w['w3'], f['b3d'], residual=idn, relu=True)
+        return ops.linear_bias_act(out, w['w3'], f['b3d'], residual=idn, relu=True), None
     out = self.conv3(out)
     if self.downsample is None:
-        return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True)
+        return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=x, relu=True), None
     idn = self.downsample[0](x)
     return ops.channel_affine_act_(out, f['s3'], f['b3'], residual=idn, res_scale=f['sd'],
-                                   res_shift=f['bd'], relu=True)
+                                   res_shift=f['bd'], relu=True), None
+
+
+def _chain_ok(blk, nxt, x):
+    """can `blk`'s conv3 + add + ReLU and `nxt`'s conv1 + ReLU run as one kernel on input x?"""
+    f, g = getattr(blk, '_ia_fused', None), getattr(nxt, '_ia_fused', None)
+    if f is None or g is None or 'w3' not in f or 'w1' not in g or nxt.downsample is not None:
+        return False
+    if blk.downsample is not None and 'wd' not in f:
+        return False
+    k, n = f['w3'].shape
+    return tuple(g['w1'].shape) == (n, g['w1'].shape[1]) and ops.chain_usable(x, k, n, g['w1'].shape[1]) \
+        and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def _layer_forward(self, x):
+    """a residual stage (nn.Sequential of bottlenecks, resnet.py:106-123): the blocks one after the
+    other, and where two consecutive blocks allow it (stage 1 at the benchmark sizes) the boundary
+    between them in ONE kernel -- the tail of block i also produces conv1 of block i + 1"""
+    blocks = list(self)
+    if not all(isinstance(b, Bottleneck) and hasattr(b, '_ia_opts') for b in blocks) or not blocks:
+        return torch.nn.Sequential.forward(self, x)
+    h1 = None
+    for i, blk in enumerate(blocks):
+        nb = blocks[i + 1] if i + 1 < len(blocks) else None
+        chain = nb is not None and x.dtype == torch.float32 and _chain_ok(blk, nb, x) \
+            and _fast(blk, x) and _fast(nb, x) and _chain_ok(blk, nb, x)     # (a re-fold replaces the dicts)
+        if chain or h1 is not None:
+            x, h1 = _bottleneck_run(blk, x, h1=h1, nxt=nb._ia_fused if chain else None)
+        else:
+            x = blk(x)
+    return x
 
 
 def _weights_for(f, dtype):
@@ -490,6 +535,11 @@ def fuse_inference(model, winograd=False, train=False):
         if isinstance(m, ResNet):
             m._stem = types.MethodType(_resnet_stem, m)
             m._stages = types.MethodType(_resnet_stages, m)
+            if winograd:
+                for name in m.res_layers:
+                    layer = getattr(m, name)
+                    layer._ia_layer = True
+                    layer.forward = types.MethodType(_layer_forward, layer)
         n += 1
     return n
 
@@ -506,6 +556,9 @@ def refresh_fused(model):
 
 def unfuse_inference(model):
     for m in model.modules():
+        if hasattr(m, '_ia_layer'):
+            del m._ia_layer
+            m.__dict__.pop('forward', None)
         for attr in ('_ia_fused', '_ia_wino', '_ia_c3', '_ia_opts', '_ia_stamp', '_ia_dirty'):
             if hasattr(m, attr):
                 delattr(m, attr)

@@ -695,6 +695,41 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
     return out
 
 
+def conv1x1_chain(x, w_kn, bias, residual, w2_kn, bias2):
+    """the boundary between two stage-1 bottlenecks in one pass (csrc/conv1x1_stream.hip,
+    k_conv1x1_chain): y = relu(x . w_kn + bias + residual), h = relu(y . w2_kn + bias2) computed from
+    the accumulators of the first product -> (y, h), both channels-last fp32"""
+    _require_gpu(x, 'x')
+    B, k, H, W = x.shape
+    n, n2 = int(w_kn.shape[1]), int(w2_kn.shape[1])
+    if x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) \
+            or (k, n, n2) != _CHAIN_SHAPE or tuple(w_kn.shape) != (k, n) or tuple(w2_kn.shape) != (n, n2) \
+            or w_kn.dtype != torch.float32 or w2_kn.dtype != torch.float32 \
+            or not w_kn.is_contiguous() or not w2_kn.is_contiguous():
+        raise TypeError('conv1x1_chain: fp32 channels-last input, (k, n, n2) = %s' % (_CHAIN_SHAPE,))
+    for b_, n_ in ((bias, n), (bias2, n2)):
+        if b_ is not None and (b_.dtype != torch.float32 or b_.numel() != n_ or not b_.is_contiguous()):
+            raise TypeError('conv1x1_chain: biases are contiguous fp32 vectors of the output widths')
+    y = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    h = torch.empty((B, n2, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (tuple(residual.shape) != tuple(y.shape) or residual.dtype != torch.float32
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError('residual must be a channels-last fp32 tensor of the output shape')
+    _lib.check(_lib.lib().ia_conv1x1_chain(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(w2_kn),
+                                           _ptr(bias2), _ptr(y), _ptr(h), B * H * W, k, n, n2, _stream()),
+               'ia_conv1x1_chain')
+    return y, h
+
+
+_CHAIN_SHAPE = (64, 256, 64)
+CHAIN_1X1 = True                       # fuse._layer_forward chains stage-1 block boundaries
+
+
+def chain_usable(x, k, n, n2):
+    return CHAIN_1X1 and STREAM_1X1 and x.dtype == torch.float32 and (k, n, n2) == _CHAIN_SHAPE \
+        and x.shape[0] * x.shape[2] * x.shape[3] >= 65536
+
+
 _col_cache = {}
 
 

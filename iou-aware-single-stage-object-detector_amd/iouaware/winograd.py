@@ -142,6 +142,10 @@ def output_transform(plan, m, channels, groups, bias, relu, segments):
 _LT_WS_BYTES = 128 << 20
 
 
+STREAM_BMM = True
+_STREAM_BMM_SHAPES = ((64, 64),)      # (128, 128) and (256, 48) measured slower than the library: 137 / 148 vs 124 / 139 us
+
+
 def batched_gemm(v, u, out):
     """out[b] = v[b] @ u[b] through hipBLASLt (csrc/gemm.hip); the kernel of a shape comes from the
     committed tuning table (ops.gemm_table_load: found offline by timing the library's candidates,
@@ -152,6 +156,12 @@ def batched_gemm(v, u, out):
     n = u.shape[2]
     if not (v.is_contiguous() and u.is_contiguous() and out.is_contiguous()):
         raise ValueError('batched_gemm needs contiguous stacks')
+    if STREAM_BMM and (k, n) in _STREAM_BMM_SHAPES and rows >= 4096 and v.dtype == torch.float32:
+        # HBM-bound products (<= 16 K weights per matrix): this library's streaming MFMA kernel,
+        # weights in LDS -- the library's kernels reach 3.4 TB/s on these shapes
+        _lib.check(_lib.lib().ia_batched_gemm_stream(_ptr(v), _ptr(u), _ptr(out), int(batch), int(rows),
+                                                     int(k), int(n), _stream()), 'ia_batched_gemm_stream')
+        return out
     ws = _scratch(v.device, 'lt_ws', (_LT_WS_BYTES // 4,))
     _lib.check(_lib.lib().ia_batched_gemm(_ptr(v), _ptr(u), _ptr(out), int(batch), int(rows), int(k),
                                           int(n), _ptr(ws), _LT_WS_BYTES, _stream()),

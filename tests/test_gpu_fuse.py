@@ -221,3 +221,69 @@ def test_conv1x1_stream_matches_fp64(k, n, res):
     finally:
         ops.STREAM_1X1 = True
     assert float((a - lib).abs().max()) < 1e-5 * float(lib.abs().max())
+
+
+@pytest.mark.parametrize('res', [True, False])
+def test_conv1x1_chain_equals_the_two_kernels(res):
+    """the block-boundary kernel (conv3 + add + ReLU -> y, next conv1 + ReLU -> h from the
+    accumulators): the same bits as the two streaming kernels it replaces, and the fp64 products;
+    partial last tile"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(3, 64, 37, 53, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 256, device='cuda', generator=g) * 0.1
+    b = torch.randn(256, device='cuda', generator=g)
+    w2 = torch.randn(256, 64, device='cuda', generator=g) * 0.05
+    b2 = torch.randn(64, device='cuda', generator=g)
+    r = torch.randn(3, 256, 37, 53, device='cuda', generator=g).contiguous(memory_format=torch.channels_last) if res else None
+    y, h = ops.conv1x1_chain(x, w, b, r, w2, b2)
+    y0 = ops.conv1x1_stream(x, w, b, residual=r, relu=True)
+    h0 = ops.conv1x1_stream(y0, w2, b2, relu=True)
+    assert y.is_contiguous(memory_format=torch.channels_last) and h.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, y0) and torch.equal(h, h0)
+    want = torch.einsum('bkhw,kn->bnhw', x.double(), w.double()) + b.double().view(1, -1, 1, 1)
+    if res:
+        want = want + r.double()
+    want = want.clamp(min=0)
+    wh = (torch.einsum('bkhw,kn->bnhw', want, w2.double()) + b2.double().view(1, -1, 1, 1)).clamp(min=0)
+    assert float((y.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert float((h.double() - wh).abs().max()) < 1e-5 * float(wh.abs().max())
+    y, h = ops.conv1x1_chain(x, w, None, None, w2, None)            # no biases, no residual
+    y0 = ops.conv1x1_stream(x, w, None, relu=True)
+    assert torch.equal(y, y0) and torch.equal(h, ops.conv1x1_stream(y0, w2, None, relu=True))
+
+
+def test_stage1_chained_boundaries_equal_unchained():
+    """fuse._layer_forward: ResNet-50 stage 1 with the block boundaries chained (the tail of block i
+    also produces conv1 of block i + 1) against the same blocks one kernel per convolution -- same
+    bits; smaller inputs and the other stages take the unchained route"""
+    from iouaware import ops
+    from iouaware.backbones import ResNet
+    from iouaware.fuse import fuse_inference
+    torch.manual_seed(3)
+    net = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, style='pytorch').cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    fuse_inference(net, winograd=True)
+    x = torch.randn(2, 3, 736, 800, device='cuda').contiguous(memory_format=torch.channels_last)   # stage 1: 2 x 184 x 200
+    calls = []
+    orig = ops.conv1x1_chain
+    ops.conv1x1_chain = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            a = net(x)
+            n_chained = len(calls)
+            ops.CHAIN_1X1 = False
+            b = net(x)
+            assert len(calls) == n_chained
+            small = net(x[:, :, :256, :320].contiguous(memory_format=torch.channels_last))
+            assert len(calls) == n_chained                  # below the streaming kernels' size: unchained
+    finally:
+        ops.CHAIN_1X1 = True
+        ops.conv1x1_chain = orig
+    assert n_chained == 2                                   # block 0 -> 1, block 1 -> 2
+    assert len(small) == 4
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

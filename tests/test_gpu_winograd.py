@@ -110,3 +110,28 @@ def test_whole_network_winograd_matches_module_path():
             assert v.is_contiguous(memory_format=torch.channels_last)
             e = float((u - v).abs().max() / u.abs().max())
             assert e < 1e-4, e
+
+
+@pytest.mark.parametrize('k,n,batch,rows', [(64, 64, 36, 4200), (128, 128, 36, 4111), (256, 48, 36, 5000)])
+def test_batched_gemm_stream_matches_fp64_and_library(k, n, batch, rows):
+    """the HBM-bound Winograd-domain products on the streaming MFMA kernel (one grid row per matrix,
+    weights in LDS) against fp64 and against the library's batched GEMM; rows % 16 != 0"""
+    from iouaware import winograd as wg
+    g = torch.Generator(device='cuda').manual_seed(k + n)
+    v = torch.randn(batch, rows, k, device='cuda', generator=g)
+    u = torch.randn(batch, k, n, device='cuda', generator=g) * 0.1
+    out = torch.full((batch, rows, n), float('nan'), device='cuda')
+    if (k, n) in wg._STREAM_BMM_SHAPES:
+        wg.batched_gemm(v, u, out)                          # routed to ia_batched_gemm_stream
+    else:                                                   # instantiated, not routed (slower than the library)
+        from iouaware import _lib
+        from iouaware.ops import _ptr, _stream
+        _lib.check(_lib.lib().ia_batched_gemm_stream(_ptr(v), _ptr(u), _ptr(out), batch, rows, k, n, _stream()), 'bgs')
+    want = torch.bmm(v.double(), u.double())
+    assert float((out.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    wg.STREAM_BMM = False
+    try:
+        lib = wg.batched_gemm(v, u, torch.empty_like(out))
+    finally:
+        wg.STREAM_BMM = True
+    assert float((out - lib).abs().max()) < 1e-5 * float(lib.abs().max())

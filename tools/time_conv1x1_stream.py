@@ -29,3 +29,20 @@ for k, n, res in ((64, 256, True), (256, 64, False), (64, 64, False), (64, 256, 
     t1 = bench(lambda: ops.conv1x1_stream(x, w, b, residual=r, relu=True))
     print('%3d -> %3d res=%d  %.0f MB  library %.1f us (%.2f TB/s)   own %.1f us (%.2f TB/s)   max rel diff %.1e'
           % (k, n, res, mb, t0 * 1e3, mb / t0 / 1e3, t1 * 1e3, mb / t1 / 1e3, err), flush=True)
+
+# the block boundary in one kernel (k_conv1x1_chain) against the two kernels it replaces
+x = torch.randn(B, 64, H, W, device='cuda').contiguous(memory_format=cl)
+w = torch.randn(64, 256, device='cuda') * 0.05
+b = torch.randn(256, device='cuda')
+w2 = torch.randn(256, 64, device='cuda') * 0.05
+b2 = torch.randn(64, device='cuda')
+r = torch.randn(B, 256, H, W, device='cuda').contiguous(memory_format=cl)
+def two():
+    y = ops.conv1x1_stream(x, w, b, residual=r, relu=True)
+    return y, ops.conv1x1_stream(y, w2, b2, relu=True)
+y0, h0 = two()
+y1, h1 = ops.conv1x1_chain(x, w, b, r, w2, b2)
+t0, t1 = bench(two), bench(lambda: ops.conv1x1_chain(x, w, b, r, w2, b2))
+mb = (x.numel() + r.numel() + y0.numel() + h0.numel()) * 4 / 1e6
+print('boundary 64 -> 256 (+res) -> 64: two kernels %.1f us, chained %.1f us (%.0f MB, %.2f TB/s); same bits: %s'
+      % (t0 * 1e3, t1 * 1e3, mb, mb / t1 / 1e3, torch.equal(y0, y1) and torch.equal(h0, h1)), flush=True)
