@@ -140,6 +140,14 @@ def _bottleneck_run(self, x, h1=None, nxt=None):
     elif wino is not None and wino.usable(out):
         # (conv1's BN + ReLU on load,) conv2 + its folded BN + ReLU in the Winograd path
         out = wino(out, pre=pre)
+    elif pre is None and 'c3' in f and out.dtype == torch.bfloat16 \
+            and out.is_contiguous(memory_format=torch.channels_last):
+        # bf16 (BASELINE config 3): conv2 + folded BN + ReLU on this library's MFMA implicit-GEMM
+        # kernel (csrc/conv3x3_bf16.hip; weights packed once per fold, BN scale folded in)
+        wp = f.get('_c3_packed')
+        if wp is None:
+            wp = f['_c3_packed'] = ops.conv3x3_bf16_pack(f['c3'])
+        out = ops.conv3x3_bf16(out, wp, f['b2'], self.conv2.out_channels, relu=True)
     elif lt and 'im2col2' in f and out.is_contiguous(memory_format=torch.channels_last):
         # stride-2 conv2 (first block of stages 2-4): im2col + library GEMM, folded BN + ReLU in
         # the epilogue -- a fixed reduction order, where the library convolution's split-K kernels
@@ -276,6 +284,12 @@ def _convmodule_forward(self, x, activate=True, norm=True):
     wino = f.get('wino')
     if wino is not None and wino.relu == relu and wino.usable(x):
         return wino(x)
+    if 'c3' in f and norm and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+        # bf16 FPN output convolutions: the MFMA implicit-GEMM kernel, bias (+ReLU) in its epilogue
+        wp = f.get('_c3_packed')
+        if wp is None:
+            wp = f['_c3_packed'] = ops.conv3x3_bf16_pack(f['c3'])
+        return ops.conv3x3_bf16(x, wp, f.get('bias'), self.conv.out_channels, relu=relu)
     if 'w_kn' in f and norm and x.dtype in (torch.float32, torch.bfloat16) \
             and x.is_contiguous(memory_format=torch.channels_last):
         return ops.linear_bias_act(x, _weights_for(f, x.dtype)['w_kn'], f['b_kn'], relu=relu)
@@ -436,6 +450,9 @@ def _fold(m):
             with torch.no_grad():           # BN scale folded into the weights, shift = bias
                 w2 = m.conv2.weight.float() * f['s2'].view(-1, 1, 1, 1)
             f['wino2'] = WinogradConv3x3(w2, f['b2'], relu=True)
+            if m.conv2.in_channels % 32 == 0 and m.conv2.out_channels % 2 == 0 \
+                    and getattr(m.conv2, 'padding_mode', 'zeros') == 'zeros':
+                f['c3'] = w2                # bf16 networks: packed for k_conv3x3_bf16 at the first bf16 call
         m._ia_fused = f
     elif isinstance(m, BasicBlock):
         f = {}
@@ -477,6 +494,9 @@ def _fold(m):
         if winograd and fpn_conv and not m.with_norm and _wino_ok(m.conv):
             from .winograd import WinogradConv3x3
             f['wino'] = WinogradConv3x3(m.conv.weight, m.conv.bias, relu=m.with_activatation)
+            if c.in_channels % 32 == 0 and c.out_channels % 2 == 0 \
+                    and getattr(c, 'padding_mode', 'zeros') == 'zeros':
+                f['c3'] = c.weight.detach()
         m._ia_fused = f
     else:
         return False

@@ -14,7 +14,11 @@ pytestmark = pytest.mark.gpu
     (2, 50, 84, 256, 256, True, True),        # P4: 9 x 28 tiles
     (1, 100, 168, 256, 256, False, True),     # P3: 10 x 24 tiles
     (1, 33, 17, 96, 512, True, True),         # two column blocks, Cin not a power of two
-    (8, 100, 168, 64, 512, True, True),       # 1 120 workgroups: the 256-pixel-tile kernel (smaller grids take 128-pixel tiles)
+    (8, 100, 168, 64, 512, True, True),       # two column tiles, many workgroups
+    (2, 40, 56, 64, 64, True, True),          # ResNet stage 1: the (2, 2, 2) variant, second wavefront column all padding
+    (2, 37, 53, 128, 128, True, True),        # ResNet stage 2: (2, 2, 2), 128-pixel tiles with overhang
+    (1, 25, 42, 512, 512, True, True),        # ResNet stage 4
+    (1, 20, 30, 64, 96, False, True),         # 64 < Cout <= 128, partial second column
 ])
 def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias):
     from iouaware import ops

@@ -638,23 +638,30 @@ def test_config3_r101_bf16_full_size_against_the_reference(golden_dir):
                 num += float(((a - w) ** 2).sum())
                 den += float((w ** 2).sum())
         return (num / den) ** 0.5
+    # The library's bf16 convolutions (backbone of both paths) add with atomics: the SAME model
+    # gives 62-74 (eager) / 64-78 (fused) twins from run to run.  One run against one run is a coin
+    # toss near the bound (seen failing with fused 66 / eager 74 and passing with 72 / 67 on the
+    # same code), so both sides are evaluated three times and the medians compared.
     with torch.no_grad():
         eager = copy.deepcopy(m).to(torch.bfloat16)
         xb = x.to(torch.bfloat16)
         e_rms = logits_rms(*eager.forward_head(xb))
-        eager_res = eager(return_loss=False, rescale=True, img=[xb], img_meta=[[meta]])
+        eager_runs = [_twin_retention(want, eager(return_loss=False, rescale=True, img=[xb], img_meta=[[meta]]))[1]
+                      for _ in range(3)]
         del eager
         fuse_inference(m, winograd=True)
         mb = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
         xc = xb.contiguous(memory_format=torch.channels_last)
         o_rms = logits_rms(*mb.forward_head(xc))
-        res = mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]])
-    strong, found = _twin_retention(want, res)
-    _, found_eager = _twin_retention(want, eager_res)
+        fused_runs = [_twin_retention(want, mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]]))
+                      for _ in range(3)]
+    strong = fused_runs[0][0]
+    found, found_eager = sorted(r[1] for r in fused_runs)[1], sorted(eager_runs)[1]
     _REPORT.append('config 3 (R-101 bf16) at 800x1344 vs the reference fp32 fixture: head-logit RMS error fused %.2e, '
                    'torch-bf16 %.2e | reference detections with score > 0.3: %d; twin (same class, IoU > 0.85) in the '
-                   'fused bf16 result: %d (%.0f %%), in torch\'s own bf16 result: %d'
-                   % (o_rms, e_rms, strong, found, 100.0 * found / max(strong, 1), found_eager))
+                   'fused bf16 result: %d (%.0f %%), in torch\'s own bf16 result: %d (medians of three runs: fused %s, '
+                   'torch %s)' % (o_rms, e_rms, strong, found, 100.0 * found / max(strong, 1), found_eager,
+                                 [r[1] for r in fused_runs], eager_runs))
     assert o_rms <= 2.5e-2 and o_rms <= 1.5 * e_rms + 1e-3, (o_rms, e_rms)
     assert strong >= 10
     assert found >= 0.55 * strong and found >= found_eager - 5, (strong, found, found_eager)

@@ -29,5 +29,11 @@ for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
     t0, t1 = bench(lib), bench(mine)
     fl = 2.0 * B * H * W * 256 * 256 * 9
     tot[0] += t0; tot[1] += t1
-    print('%3dx%3d  library conv + epilogue %.3f ms (%.0f TF)   own kernel %.3f ms (%.0f TF)' % (H, W, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9), flush=True)
+    var = ''
+    for v in ('42', '41', '22', '21'):          # forced tile variants (MB, WM): 256 / 128 / 128 / 64 pixels
+        os.environ['IA_CONV3_VARIANT'] = v
+        tv = bench(mine)
+        var += '  %s: %.3f (%.0f)' % (v, tv, fl / tv / 1e9)
+    del os.environ['IA_CONV3_VARIANT']
+    print('%3dx%3d  library conv + epilogue %.3f ms (%.0f TF)   own kernel %.3f ms (%.0f TF) |%s' % (H, W, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, var), flush=True)
 print('all levels: library %.3f ms, own %.3f ms' % tuple(tot))
