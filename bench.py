@@ -429,7 +429,7 @@ def train_record(device, iters=5, warmup=3, loss_part=True, find=False, channels
                          'GPU: fwd + HIP targets / losses + bwd + clip + SGD (random init, synthetic)')
 
 
-PMC_PROFILE = 'r03_head_pmc.json'
+PMC_PROFILE = 'r04_head_pmc.json'
 WINO_PMC_PROFILE = 'r03_wino_pmc.json'
 
 

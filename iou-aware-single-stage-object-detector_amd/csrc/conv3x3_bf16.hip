@@ -33,9 +33,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kCvBK = 32;                 // input channels per K step
 constexpr int kCvRow = 80;                // bytes per LDS row (64 of data)
-constexpr int kCvMaxPatch = 352;          // (TH + 2) * (TW + 2) <= this (256-pixel tiles)
-constexpr int kCvMaxPatchHalf = 208;      // ... for 128-pixel tiles
-constexpr int kCvMaxPatchQuarter = 120;   // ... for 64-pixel tiles
+// The halo patch of a TH x TW tile lies in LDS with a row pitch of TW + 16 pixels (not TW + 2): pixel
+// m = ty * TW + tx of the tile then sits in LDS row R = m + 16 ty + (tap offset), R = m (mod 16), and the
+// 16 lanes of every ds_read_b128 service group (lanes {0-3, 12-15, 20-27} ...: rows distinct mod 16)
+// fall into 16 different 16-byte bank slots whatever the tile shape.  With the dense pitch TW + 2 every
+// tile row boundary inside a 32-pixel block made two or three lanes of a group collide -- each
+// collision a whole extra LDS cycle for the group (8 x 8 tiles: 3 cycles instead of 1).
+constexpr int kCvPitchPad = 16;
+constexpr int kCvMaxRows128 = 320;        // (TH + 2) * (TW + 16) <= this for 128-pixel tiles (8 x 16, 4 x 32)
+constexpr int kCvMaxRows64 = 240;         // ... for 64-pixel tiles (8 x 8, 4 x 16, 2 x 32)
+constexpr int kCvMaxPatchPx128 = 256;     // (TH + 2) * (TW + 2) <= this: four 16-byte pieces per thread
+constexpr int kCvMaxPatchPx64 = 128;      // ... two pieces per thread (8 x 8, 4 x 16)
 constexpr int kCvBN = 256;
 
 constexpr int kCvMaxGroups = 2;
@@ -70,8 +78,9 @@ template <int MB, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
 {
     constexpr int kThreads = 64 * WM * WN;
-    constexpr int kPatch = MB * WM == 8 ? kCvMaxPatch : (MB * WM == 4 ? kCvMaxPatchHalf : kCvMaxPatchQuarter);
-    constexpr int NP = (kPatch * 4 + kThreads - 1) / kThreads;      // 16-byte patch pieces per thread (<= 4)
+    static_assert(MB * WM == 4 || MB * WM == 2, "128- or 64-pixel tiles");
+    constexpr int kPatch = MB * WM == 4 ? kCvMaxRows128 : kCvMaxRows64;          // LDS rows of one patch buffer
+    constexpr int NP = ((MB * WM == 4 ? kCvMaxPatchPx128 : kCvMaxPatchPx64) * 4 + kThreads - 1) / kThreads;   // patch pieces per thread
     static_assert(NP <= 4, "patch pieces");
     constexpr int kWM = 32 * MB;                           // pixels per wavefront
     __shared__ __attribute__((aligned(16))) unsigned char s_a[2][kPatch * kCvRow];
@@ -86,7 +95,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
     const int b = t / a.tiles_y[lv];
     const int grp = (int)blockIdx.y / a.ntile, nt = (int)blockIdx.y - grp * a.ntile;
     const int y0 = tyi * TH, x0 = txi * TW;
-    const int PW = TW + 2, npix = (TH + 2) * PW, tile_px = TH * TW;
+    const int PW = TW + 2, PWl = TW + kCvPitchPad, npix = (TH + 2) * PW, tile_px = TH * TW;
     const int nchunk = a.Cin / kCvBK, nsteps = nchunk * 9;
 
     // ---- this lane's A rows (pixels) as byte offsets into the patch (tap (0,0) corner)
@@ -96,7 +105,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
         int m = wm * kWM + mb * 32 + (lane & 31);
         m = m < tile_px ? m : tile_px - 1;                // idle rows read a valid address
         const int ty = m / TW, tx = m - ty * TW;
-        a_off[mb] = (ty * PW + tx) * kCvRow + (lane >> 5) * 16;
+        a_off[mb] = (ty * PWl + tx) * kCvRow + (lane >> 5) * 16;
     }
 
     // ---- global -> register staging (plain scalars and macros: arrays captured by a lambda went
@@ -108,8 +117,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
     const uint16_t *wbase = a.wp + (size_t)(grp * a.ntile + nt) * nsteps * (kCvBN * kCvBK) + (wn * 4 * 64 + lane) * 8;
     // patch pieces of this thread: p = u * kThreads + tid -> pixel p >> 2, 16-byte part p & 3
     const uint16_t *pa0, *pa1, *pa2, *pa3;
+    int sa_off0, sa_off1, sa_off2, sa_off3;                // LDS byte offsets of the pieces
     bool in0, in1, in2, in3, on0, on1, on2, on3;
-#define CV_PIECE(u, PA, IN, ON)                                                                     \
+#define CV_PIECE(u, PA, IN, ON, SA)                                                                 \
     {                                                                                               \
         int p = u * kThreads + tid;                                                                 \
         ON = p < npix * 4;                                                                          \
@@ -120,18 +130,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
         IN = ON && iy >= 0 && iy < H && ix >= 0 && ix < W;                                      \
         const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix); \
         PA = xb + ((size_t)cy * W + cx) * a.xs + part * 8;                                       \
+        SA = (py * PWl + pxx) * kCvRow + part * 16;                                                 \
     }
-    CV_PIECE(0, pa0, in0, on0)
-    CV_PIECE(1, pa1, in1, on1)
-    if (NP > 2) CV_PIECE(2, pa2, in2, on2) else { pa2 = pa1; in2 = on2 = false; }
-    if (NP > 3) CV_PIECE(3, pa3, in3, on3) else { pa3 = pa1; in3 = on3 = false; }
+    CV_PIECE(0, pa0, in0, on0, sa_off0)
+    CV_PIECE(1, pa1, in1, on1, sa_off1)
+    if (NP > 2) CV_PIECE(2, pa2, in2, on2, sa_off2) else { pa2 = pa1; in2 = on2 = false; sa_off2 = 0; }
+    if (NP > 3) CV_PIECE(3, pa3, in3, on3, sa_off3) else { pa3 = pa1; in3 = on3 = false; sa_off3 = 0; }
 #undef CV_PIECE
     // (an AND with a per-piece mask: `in ? value : zero` on a 128-bit value became a table in scratch)
     const uint32_t mk0 = in0 ? 0xffffffffu : 0u, mk1 = in1 ? 0xffffffffu : 0u, mk2 = in2 ? 0xffffffffu : 0u,
                    mk3 = in3 ? 0xffffffffu : 0u;
-    const int sa_off0 = (tid >> 2) * kCvRow + (tid & 3) * 16;
-    const int sa_off1 = sa_off0 + (kThreads >> 2) * kCvRow, sa_off2 = sa_off1 + (kThreads >> 2) * kCvRow,
-              sa_off3 = sa_off2 + (kThreads >> 2) * kCvRow;
     uint4 ra0, ra1, ra2 = make_uint4(0u, 0u, 0u, 0u), ra3 = make_uint4(0u, 0u, 0u, 0u);
     uint4 bx0, bx1, bx2, bx3, by0, by1, by2, by3, bz0, bz1, bz2, bz3;     // weight fragments (j, kk) = (0,0) (0,1) (1,0) (1,1)
 #define CV_LOAD_A(chunk)                                                                            \
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
            left to it: each pair read right in front of its two MFMAs measured FASTER than all    \
            eight requested at the head of the step (0.363 against 0.396 ms on 100 x 168) */        \
         __builtin_amdgcn_sched_barrier(0);                                                          \
-        const unsigned char *ab = s_a[0] + cur * (kPatch * kCvRow) + (dy * PW + dx) * kCvRow;       \
+        const unsigned char *ab = s_a[0] + cur * (kPatch * kCvRow) + (dy * PWl + dx) * kCvRow;      \
         CV_MFMA(0, X0, X2)                                                                          \
         CV_MFMA(1, X1, X3)                                                                          \
         if ((TAP) == 6) CV_STORE_A(cur ^ 1)                                                         \
@@ -286,33 +294,36 @@ __global__ void __launch_bounds__(256) k_conv3x3_pack(const uint16_t *w, uint16_
     wp[idx] = co < Cout ? w[(((size_t)(g * Cout + co) * 9) + tap) * Cin + chunk * kCvBK + k] : (uint16_t)0;
 }
 
-// tile shape for an H x W map: TH * TW <= max_px, patch <= max_patch, least overhang
-static void conv3_tile_shape_search(int H, int W, int max_px, int max_patch, int &TH, int &TW);
+// tile shape for an H x W map: TH * TW <= max_px, (TH + 2) * (TW + 16) <= max_rows LDS rows,
+// (TH + 2) * (TW + 2) <= the patch pixels of the tile size; least overhang
+static void conv3_tile_shape_search(int H, int W, int max_px, int max_rows, int &TH, int &TW);
 
-// memoised per (H, W, tile size): the search walks ~3 800 shapes, twice per level and launch
-static void conv3_tile_shape(int H, int W, int max_px, int max_patch, int &TH, int &TW)
+// memoised per (H, W, tile size): the search walks ~3 800 shapes per level and launch
+static void conv3_tile_shape(int H, int W, int max_px, int max_rows, int &TH, int &TW)
 {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> memo;
-    const auto key = std::make_tuple(H, W, max_px, max_patch);
+    const auto key = std::make_tuple(H, W, max_px, max_rows);
     {
         std::lock_guard<std::mutex> lock(mu);
         auto it = memo.find(key);
         if (it != memo.end()) { TH = it->second.first; TW = it->second.second; return; }
     }
-    conv3_tile_shape_search(H, W, max_px, max_patch, TH, TW);
+    conv3_tile_shape_search(H, W, max_px, max_rows, TH, TW);
     std::lock_guard<std::mutex> lock(mu);
     if (memo.size() > 4096) memo.clear();
     memo[key] = std::make_pair(TH, TW);
 }
 
-static void conv3_tile_shape_search(int H, int W, int max_px, int max_patch, int &TH, int &TW)
+static void conv3_tile_shape_search(int H, int W, int max_px, int max_rows, int &TH, int &TW)
 {
     double best = -1.0;
-    TH = 8; TW = 16;
+    TH = 4; TW = 16;
     for (int tw = 4; tw <= 64; ++tw) {
         for (int th = 2; th <= 64; ++th) {
-            if (th * tw > max_px || (th + 2) * (tw + 2) > max_patch) continue;
+            if (th * tw > max_px || (th + 2) * (tw + kCvPitchPad) > max_rows ||
+                (th + 2) * (tw + 2) > (max_px == 128 ? kCvMaxPatchPx128 : kCvMaxPatchPx64))
+                continue;
             const int64_t ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
             const double eff = (double)H * W / ((double)ty * tx * max_px);      // useful rows per tile
             if (eff > best + 1e-9) { best = eff; TH = th; TW = tw; }
@@ -378,7 +389,7 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     if (force && force[0] == '4' && force[1] == '1' && wnc == 4) mb = 4;
     {
         const int px = 32 * mb * wmr;
-        const int patch = px == 256 ? ia::kCvMaxPatch : (px == 128 ? ia::kCvMaxPatchHalf : ia::kCvMaxPatchQuarter);
+        const int patch = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
         for (int l = 0; l < d->num_levels; ++l) {
             ia::conv3_tile_shape(a.H[l], a.W[l], px, patch, a.TH[l], a.TW[l]);
             a.tiles_y[l] = (a.H[l] + a.TH[l] - 1) / a.TH[l]; a.tiles_x[l] = (a.W[l] + a.TW[l] - 1) / a.TW[l];

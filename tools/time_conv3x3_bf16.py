@@ -30,7 +30,7 @@ for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
     fl = 2.0 * B * H * W * 256 * 256 * 9
     tot[0] += t0; tot[1] += t1
     var = ''
-    for v in ('42', '41', '22', '21'):          # forced tile variants (MB, WM): 256 / 128 / 128 / 64 pixels
+    for v in ('41',):                           # forced variant (4, 1, 4): 128-pixel tiles
         os.environ['IA_CONV3_VARIANT'] = v
         tv = bench(mine)
         var += '  %s: %.3f (%.0f)' % (v, tv, fl / tv / 1e9)
