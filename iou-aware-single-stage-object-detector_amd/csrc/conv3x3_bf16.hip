@@ -44,6 +44,7 @@ constexpr int kCvMaxRows128 = 320;        // (TH + 2) * (TW + 16) <= this for 12
 constexpr int kCvMaxRows64 = 240;         // ... for 64-pixel tiles (8 x 8, 4 x 16, 2 x 32)
 constexpr int kCvMaxPatchPx128 = 256;     // (TH + 2) * (TW + 2) <= this: four 16-byte pieces per thread
 constexpr int kCvMaxPatchPx64 = 128;      // ... two pieces per thread (8 x 8, 4 x 16)
+constexpr int kCvBigTiles = 2048;         // maps with this many 128-pixel tiles in the batch take (4, 1, 4)
 constexpr int kCvBN = 256;
 
 constexpr int kCvMaxGroups = 2;
@@ -358,53 +359,68 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         d->x_stride < d->cin || (d->x_stride & 7) || d->y_stride < d->cout || (d->y_stride & 1))
         return IA_E_ARG;
     if ((uintptr_t)wp & 15u) return IA_E_ARG;
-    ia::Conv3Args a;
-    memset(&a, 0, sizeof(a));
-    a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
-    a.L = d->num_levels; a.B = d->batch; a.Cin = d->cin; a.Cout = d->cout; a.xs = d->x_stride; a.ys = d->y_stride;
-    a.relu = relu ? 1 : 0; a.ntile = (d->cout + ia::kCvBN - 1) / ia::kCvBN;
     for (int l = 0; l < d->num_levels; ++l) {
         if (d->H[l] < 1 || d->W[l] < 1) return IA_E_ARG;
-        a.H[l] = d->H[l]; a.W[l] = d->W[l];
-        for (int g = 0; g < d->groups; ++g) {
+        for (int g = 0; g < d->groups; ++g)
             if (!d->x[g][l] || !d->y[g][l] || ((uintptr_t)d->x[g][l] & 15u) || ((uintptr_t)d->y[g][l] & 3u))
                 return IA_E_ARG;
-            a.x[g][l] = static_cast<const uint16_t *>(d->x[g][l]);
-            a.y[g][l] = static_cast<uint16_t *>(d->y[g][l]);
-        }
     }
     // Variant (MB, WM, WN): four wavefronts, tile = 32 * MB * WM pixels x 64 * WN channels.
     //   Cout > 128: (2, 1, 4), 64-pixel tiles, three workgroups per CU -- measured best or tied on every
-    //   pyramid level (batch 16, 256 -> 256: 100 x 168 0.324 ms against 0.325 for (4, 1, 4) and 0.368 /
-    //   0.389 for the 8-wavefront workgroups of 256 / 128 pixels; 50 x 84 0.097 against 0.113 / 0.139 /
-    //   0.123; 13 x 21 0.026 against 0.042 / 0.057 / 0.035);
+    //   pyramid level against the 8-wavefront workgroups of round 3 (batch 16, 256 -> 256: 100 x 168
+    //   0.319 ms against 0.368 / 0.389 for 256 / 128 pixels; 50 x 84 0.095 against 0.139 / 0.123;
+    //   13 x 21 0.026 against 0.057 / 0.035); LARGE maps -- at least kCvBigTiles 128-pixel tiles in
+    //   the batch -- take (4, 1, 4) in a launch of their own: half the weight-fragment traffic per
+    //   pixel (100 x 168 at batch 16: 0.305 against 0.319 ms; 50 x 84: 0.112 against 0.095, stays);
     //   Cout <= 128: (2, 2, 2), 128-pixel tiles x 128 channels -- the ResNet stage-2 / stage-1
     //   bottlenecks (64 output channels: the second column of wavefronts multiplies zeros; a
     //   256-pixel x 64-channel tile would need six patch pieces per thread).
-    // IA_CONV3_VARIANT=41 forces (4, 1, 4) where WN = 4 applies (tools/time_conv3x3_bf16.py).
-    int64_t tiles = 0;
+    // IA_CONV3_VARIANT = 41 / 21 forces (4, 1, 4) / (2, 1, 4) for every map where WN = 4 applies
+    // (tools/time_conv3x3_bf16.py).
     const int wnc = d->cout <= 128 ? 2 : 4, wmr = 4 / wnc;
-    int mb = 2;
     const char *force = getenv("IA_CONV3_VARIANT");
-    if (force && force[0] == '4' && force[1] == '1' && wnc == 4) mb = 4;
-    {
-        const int px = 32 * mb * wmr;
-        const int patch = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
-        for (int l = 0; l < d->num_levels; ++l) {
-            ia::conv3_tile_shape(a.H[l], a.W[l], px, patch, a.TH[l], a.TW[l]);
-            a.tiles_y[l] = (a.H[l] + a.TH[l] - 1) / a.TH[l]; a.tiles_x[l] = (a.W[l] + a.TW[l] - 1) / a.TW[l];
-            a.tile_off[l] = (int32_t)tiles;
-            tiles += (int64_t)d->batch * a.tiles_y[l] * a.tiles_x[l];
-            if (tiles > 2147483647LL) return IA_E_ARG;
-        }
-    }
-    for (int l = d->num_levels; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
-    const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
+    const int forced = (force && force[0] && force[1] == '1') ? force[0] - '0' : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
-    else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 2, 2>), grid, dim3(256), 0, st, a);
-    return ia::hip_status(hipGetLastError());
+    for (int pass = 0; pass < 2; ++pass) {            // pass 0: the large maps on (4, 1, 4); pass 1: the rest
+        const int mb = (pass == 0 && wnc == 4) ? 4 : 2;
+        const int px = 32 * mb * wmr;
+        const int rows = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
+        ia::Conv3Args a;
+        memset(&a, 0, sizeof(a));
+        a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
+        a.B = d->batch; a.Cin = d->cin; a.Cout = d->cout; a.xs = d->x_stride; a.ys = d->y_stride;
+        a.relu = relu ? 1 : 0; a.ntile = (d->cout + ia::kCvBN - 1) / ia::kCvBN;
+        int64_t tiles = 0;
+        int n = 0;
+        for (int l = 0; l < d->num_levels; ++l) {
+            int th, tw;
+            ia::conv3_tile_shape(d->H[l], d->W[l], 128, ia::kCvMaxRows128, th, tw);
+            const int64_t big_tiles = (int64_t)d->batch * ((d->H[l] + th - 1) / th) * ((d->W[l] + tw - 1) / tw);
+            const bool big = wnc == 4 && (forced == 4 || (forced != 2 && big_tiles >= ia::kCvBigTiles));
+            if (big != (pass == 0)) continue;
+            a.H[n] = d->H[l]; a.W[n] = d->W[l];
+            for (int g = 0; g < d->groups; ++g) {
+                a.x[g][n] = static_cast<const uint16_t *>(d->x[g][l]);
+                a.y[g][n] = static_cast<uint16_t *>(d->y[g][l]);
+            }
+            ia::conv3_tile_shape(a.H[n], a.W[n], px, rows, a.TH[n], a.TW[n]);
+            a.tiles_y[n] = (a.H[n] + a.TH[n] - 1) / a.TH[n]; a.tiles_x[n] = (a.W[n] + a.TW[n] - 1) / a.TW[n];
+            a.tile_off[n] = (int32_t)tiles;
+            tiles += (int64_t)d->batch * a.tiles_y[n] * a.tiles_x[n];
+            if (tiles > 2147483647LL) return IA_E_ARG;
+            ++n;
+        }
+        if (n == 0) continue;
+        a.L = n;
+        for (int l = n; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
+        const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
+        if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
+        else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 2, 2>), grid, dim3(256), 0, st, a);
+        const int rc = ia::hip_status(hipGetLastError());
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -30,7 +30,7 @@ for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
     fl = 2.0 * B * H * W * 256 * 256 * 9
     tot[0] += t0; tot[1] += t1
     var = ''
-    for v in ('41',):                           # forced variant (4, 1, 4): 128-pixel tiles
+    for v in ('41', '21'):                      # forced variants (4, 1, 4) / (2, 1, 4): 128- / 64-pixel tiles
         os.environ['IA_CONV3_VARIANT'] = v
         tv = bench(mine)
         var += '  %s: %.3f (%.0f)' % (v, tv, fl / tv / 1e9)
