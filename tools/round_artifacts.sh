@@ -21,8 +21,8 @@ bash $ROOT/tools/collect_wino_pmc.sh > $OUT/wino_pmc.log 2>&1
 cp $ROOT/gpurun_out/pmc/wino_pmc.json $OUT/wino_pmc.json
 bash $ROOT/tools/collect_train_pmc.sh > $OUT/train_pmc.log 2>&1
 cp $ROOT/gpurun_out/pmc/train_pmc.json $OUT/train_pmc.json
-bash $ROOT/tools/profile_config3.sh > $OUT/profile_config3.log 2>&1
-cp $ROOT/gpurun_out/profile/config3_step_summary.txt $OUT/config3_r101_bf16_b16_step_summary.txt 2>/dev/null
+bash $ROOT/tools/profile_config.sh r101-bf16 > $OUT/profile_config3.log 2>&1
+cp $ROOT/gpurun_out/profile/r101-bf16_step_summary.txt $OUT/config3_r101_bf16_b16_half_step_summary.txt 2>/dev/null
 bash $ROOT/tools/profile_x101.sh > $OUT/profile_x101.log 2>&1
 cp $ROOT/gpurun_out/profile/x101_step_summary.txt $OUT/x101_64x4d_third_step_summary.txt 2>/dev/null
 python $ROOT/tools/try_configs.py > $OUT/other_configs.txt 2>&1
