@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t bf16_rne(float f)
 // 8-wavefront workgroup of round 3, alone on its CU, ran 12-40 % slower).  WN = 4 for Cout > 128;
 // the narrow backbone layers turn column wavefronts into row wavefronts (WN = 2 / 1).
 template <int MB, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN, 2) k_conv3x3_bf16(Conv3Args a)
+__global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(Conv3Args a)
 {
     constexpr int kThreads = 64 * WM * WN;
     static_assert(MB * WM == 4 || MB * WM == 2, "128- or 64-pixel tiles");
@@ -380,9 +380,10 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     const int wnc = d->cout <= 128 ? 2 : 4, wmr = 4 / wnc;
     const char *force = getenv("IA_CONV3_VARIANT");
     const int forced = (force && force[0] && force[1] == '1') ? force[0] - '0' : 0;
+    const bool narrow64 = wnc == 2 && !(force && force[0] == '2' && force[1] == '2');     // EXPERIMENT: (1, 2, 2) unless "22"
     hipStream_t st = (hipStream_t)stream;
     for (int pass = 0; pass < 2; ++pass) {            // pass 0: the large maps on (4, 1, 4); pass 1: the rest
-        const int mb = (pass == 0 && wnc == 4) ? 4 : 2;
+        const int mb = (pass == 0 && wnc == 4) ? 4 : (narrow64 ? 1 : 2);
         const int px = 32 * mb * wmr;
         const int rows = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
         ia::Conv3Args a;
@@ -416,6 +417,7 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
         if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
         else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
+        else if (mb == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 2, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 2, 2>), grid, dim3(256), 0, st, a);
         const int rc = ia::hip_status(hipGetLastError());
         if (rc) return rc;
