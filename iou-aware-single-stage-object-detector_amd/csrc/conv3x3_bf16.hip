@@ -377,14 +377,20 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     //   256-pixel x 64-channel tile would need six patch pieces per thread).
     // IA_CONV3_VARIANT = 41 / 21 forces (4, 1, 4) / (2, 1, 4) for every map where WN = 4 applies
     // (tools/time_conv3x3_bf16.py).
-    const int wnc = d->cout <= 128 ? 2 : 4, wmr = 4 / wnc;
+    const int wnc = d->cout <= 64 ? 1 : (d->cout <= 128 ? 2 : 4);
     const char *force = getenv("IA_CONV3_VARIANT");
     const int forced = (force && force[0] && force[1] == '1') ? force[0] - '0' : 0;
-    const bool narrow64 = wnc == 2 && !(force && force[0] == '2' && force[1] == '2');     // EXPERIMENT: (1, 2, 2) unless "22"
+    // Cout <= 64: (1, 4, 1) -- four wavefronts of 32 pixels x 64 channels, no padded MFMAs (ResNet
+    // stage 1, batch 16, 200 x 336: 0.168 ms against 0.269 for (2, 2, 2) and 0.246 for (1, 2, 2));
+    // 64 < Cout <= 128 stays on (2, 2, 2) (100 x 168: 0.123 against 0.128 for (1, 2, 2)).  "22" forces
+    // (2, 2, 2) for both, "12" forces (1, 2, 2) for 64 < Cout <= 128.
+    const bool f22 = force && force[0] == '2' && force[1] == '2', f12 = force && force[0] == '1' && force[1] == '2';
+    const bool narrow64 = (wnc == 1 && !f22) || (wnc == 2 && f12);
     hipStream_t st = (hipStream_t)stream;
+    const int wnk = (wnc == 1 && !narrow64) ? 2 : wnc;         // "22" forced: 64 output channels on (2, 2, 2) as before
     for (int pass = 0; pass < 2; ++pass) {            // pass 0: the large maps on (4, 1, 4); pass 1: the rest
         const int mb = (pass == 0 && wnc == 4) ? 4 : (narrow64 ? 1 : 2);
-        const int px = 32 * mb * wmr;
+        const int px = 32 * mb * (4 / wnk);
         const int rows = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
         ia::Conv3Args a;
         memset(&a, 0, sizeof(a));
@@ -417,6 +423,7 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
         if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
         else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
+        else if (mb == 1 && wnk == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 4, 1>), grid, dim3(256), 0, st, a);
         else if (mb == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 2, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 2, 2>), grid, dim3(256), 0, st, a);
         const int rc = ia::hip_status(hipGetLastError());
