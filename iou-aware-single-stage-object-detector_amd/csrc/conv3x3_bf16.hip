@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
         /* the loads stay HERE: left alone, the scheduler sinks them to just before their use two \
            steps later (one register set, a memory round trip per step).  The A fragments are    \
            left to it: each pair read right in front of its two MFMAs measured FASTER than all    \
-           eight requested at the head of the step (0.363 against 0.396 ms on 100 x 168) */        \
+           eight requested at the head of the step (0.363 against 0.396 ms on 100 x 168), and    \
+           than a hand-pipelined order -- kk-1 fragments under the kk-0 MFMAs, the next tap's     \
+           under the kk-1 MFMAs, +8 VGPRs = 2 instead of 3 wavefronts per SIMD on the (2, 1, 4)    \
+           variant: 0.321-0.335 against 0.307-0.319 ms */                                          \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         const unsigned char *ab = s_a[0] + cur * (kPatch * kCvRow) + (dy * PWl + dx) * kCvRow;      \
         CV_MFMA(0, X0, X2)                                                                          \
