@@ -517,6 +517,64 @@ def rowmax_traffic(kernel):
         return None
 
 
+def live_stage_traffic(timeout_s=150):
+    """HBM bytes of the decode stage's kernels MEASURED IN THIS RUN (the traffic
+    figure used to come from a committed profile only): two child processes under rocprofv3 --
+    `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes, `--kernel-trace` only, as
+    MI355X_MICROARCH.md prescribes -- run tools/time_head.py (the same batch-8 launches of the head
+    path on random-init-like logits) after the timed region; traffic = 2 * FETCH_SIZE * 1024 +
+    WRITE_SIZE * 1024 (gfx950: FETCH_SIZE counts half of a wide coalesced stream).  Bounded: a
+    child that exceeds `timeout_s` is killed with its process group and the committed profile is
+    reported instead.  Returns {'stage': bytes, 'rowmax': bytes, 'kernels': {...}} or None."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    script = os.path.join(ROOT, 'tools', 'time_head.py')
+    if exe is None or not os.path.exists(script):
+        return None
+    per = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix='ia_pmc_', dir='/tmp')
+        env = dict(os.environ, TMPDIR='/tmp')
+        proc = None
+        try:
+            proc = subprocess.Popen([exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', tmp,
+                                     '--', sys.executable, script, str(BATCH), 'D', '3'], cwd='/tmp', env=env,
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            proc.wait(timeout=timeout_s)
+            files = glob.glob(os.path.join(tmp, '*', '*counter_collection.csv'))
+            if proc.returncode != 0 or not files:
+                return None
+            agg = {}
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if 'ia::' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+                        agg.setdefault(k, []).append(float(r['Counter_Value']))
+            for k, v in agg.items():
+                per.setdefault(k, {})[counter] = sum(v) / len(v)
+        except Exception:
+            if proc is not None and proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)      # the exact group started above
+                except OSError:
+                    pass
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    byts = {k: int(2 * d.get('FETCH_SIZE', 0.0) * 1024 + d.get('WRITE_SIZE', 0.0) * 1024) for k, d in per.items()}
+    stage = [k for k in byts if k.startswith(('ia::k_rowmax_filter', 'ia::k_sel_final', 'ia::k_gather_nhwc'))]
+    rowmax = [k for k in byts if k.startswith('ia::k_rowmax_nhwc')]
+    if len(stage) < 3:
+        return None
+    return dict(stage=sum(byts[k] for k in stage), rowmax=byts[rowmax[0]] if rowmax else None,
+                kernels={k: byts[k] for k in stage + rowmax})
+
+
 CONFIGS = {
     # name -> (BASELINE config, backbone overrides, images per GPU per step, torch dtype name)
     'r50': ('config 2: IoU-aware RetinaNet R-50-FPN fp32, batch 8', {}, 8, 'float32'),
@@ -728,6 +786,8 @@ def main():
                     help='r50 = BASELINE config 2 (the headline); r101-bf16 = config 3; '
                          'x101-64x4d = config 4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true',
+                    help='do not measure the decode stage HBM traffic with rocprofv3 child processes')
     ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-only', action='store_true',
                     help='print the cpu_baseline record alone (no GPU needed)')
@@ -896,6 +956,23 @@ def main():
                                     'traffic': rowmax_traffic(rm_kernel) if headline else None},
                          'wino': wino},
         }
+        # (with the CPU baseline, i.e. in the full default run only: the profiling scripts under tools/
+        # pass --no-cpu-baseline and run this file under rocprofv3 themselves -- never nest profilers)
+        under_profiler = any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+        if world == 1 and headline and not args.no_live_pmc and not args.no_cpu_baseline and not under_profiler:
+            live = live_stage_traffic()
+            if live is not None:
+                rf = out['roofline']
+                rf['traffic_committed_profile'] = rf['traffic']
+                rf['traffic'] = live['stage']
+                rf['traffic_source'] = ('measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child '
+                                        'processes (separate passes, --kernel-trace only) on the same batch-8 '
+                                        'launches (tools/time_head.py), 2 x FETCH_SIZE + WRITE_SIZE')
+                rf['traffic_kernels'] = live['kernels']
+                if live['rowmax'] is not None:
+                    rf['rowmax']['traffic'] = live['rowmax']
+            else:
+                out['roofline']['traffic_source'] += ' -- the live rocprofv3 pass of this run was not available'
         if world == 1 and headline and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         else:
