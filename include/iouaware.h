@@ -645,6 +645,14 @@ int ia_upsample2x_add_nhwc(float *fine, const float *coarse, int B, int H, int W
 int ia_upsample2x_add_nhwc_dt(void *fine, const void *coarse, int dtype, int B, int H, int W, int Hc,
                               int Wc, int C, void *stream);
 
+/* The ResNet stem convolution (resnet.py:403-414 `conv1`: 7x7 / stride 2 / pad 3, 3 -> 64, no bias;
+ * forward :506-512) on a channels-last fp32 image batch as an implicit GEMM on fp32 MFMA
+ * (csrc/stem.hip): x (B, H, W, 3), w_packed (148, 64) with row ky * 21 + kx * 3 + c = w[:, c, ky, kx]
+ * and a zero row 147, y (B, Ho, Wo, 64) = the RAW convolution, Ho = (H - 1) / 2 + 1.  The folded
+ * BatchNorm + ReLU + max-pool behind it: ia_affine_relu_maxpool_nhwc.                            */
+int ia_stem_conv7x7s2(const float *x, const float *w_packed, float *y, int B, int H, int W,
+                      void *stream);
+
 /* 1x1 convolutions of ResNet stage 1 (resnet.py:215-255, folded BatchNorm) as a streaming MFMA
  * kernel with the weights resident in LDS (csrc/conv1x1_stream.hip): y = relu?(x . w + bias
  * (+ residual)), fp32, x (rows, k), w (k, n) row-major, (k, n) in {(64, 256), (256, 64), (64, 64)}. */

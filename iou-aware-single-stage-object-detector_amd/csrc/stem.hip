@@ -1,0 +1,138 @@
+// The ResNet stem convolution -- 7x7 / stride 2 / pad 3, 3 -> 64 channels, no bias (reference
+// mmdet/models/backbones/resnet.py:403-414 `conv1`, forward :506-512) -- on channels-last fp32 as an
+// implicit GEMM on v_mfma_f32_16x16x4_f32.  It was the last convolution of the fp32 network left on
+// the library (MIOpen igemm in immediate mode: 474 us + a 69 us zero fill of the 550 MB output its
+// split-K kernel accumulates into, batch 8, 800 x 1344).
+//
+//  * K = (ky, kx, c) = 7 x 21 values per output pixel; with a channels-last 3-channel input the 21
+//    values of a kernel row are CONTIGUOUS in memory (and in the LDS patch), so k -> address is
+//    ky * row pitch + (k - 21 ky): no im2col.  K is padded 147 -> 148 (37 MFMA steps of 4) with a
+//    zero weight row.
+//  * A workgroup (4 wavefronts) owns 4 output rows x 64 output columns: the 13 x 133-pixel input
+//    patch (20.8 KB) and the whole weight matrix (148 x 64 fp32, rows padded to 80 floats: 47 KB)
+//    sit in LDS, two workgroups per CU.  A wavefront computes one output row = four 16-pixel tiles x
+//    64 channels (64 accumulator registers): per K step 4 weight reads + 4 patch reads feed 16 MFMAs.
+//  * D^T = W^T X^T like csrc/conv1x1_stream.hip: a lane ends up with FOUR CONSECUTIVE OUTPUT CHANNELS
+//    of one pixel -- 16-byte stores, 64 contiguous bytes per pixel and channel block.
+//  * The output is the RAW convolution: the folded BatchNorm + ReLU + 3x3/2 max-pool stay the one
+//    pass of k_affine_relu_maxpool (elementwise.hip).
+#include <string.h>
+#include "ia_internal.hpp"
+
+namespace ia {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4s;
+
+struct StemArgs {
+    const float *x;          // (B, H, W, 3)
+    const float *w;          // (148, 64): k = ky * 21 + kx * 3 + c, row 147 zero
+    float *y;                // (B, Ho, Wo, 64)
+    int32_t B, H, W, Ho, Wo, tiles_x, tiles_y;
+};
+
+constexpr int kStTR = 4, kStTC = 64;                 // output rows / columns per workgroup
+constexpr int kStPR = 2 * kStTR + 5;                 // 13 patch rows
+constexpr int kStPCF = (2 * kStTC + 5) * 3;          // 399 floats per patch row
+constexpr int kStPS = 400;                           // LDS pitch of a patch row (floats)
+constexpr int kStK = 148, kStLDW = 80;               // K steps * 4; LDS pitch of a weight row
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stem_conv7x7s2(StemArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_x[kStPR * kStPS];
+    __shared__ __attribute__((aligned(16))) float s_w[kStK * kStLDW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int t = blockIdx.x;
+    const int txi = t % a.tiles_x; t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int r0 = tyi * kStTR, c0 = txi * kStTC;
+    // ---- weights -> LDS (16-byte pieces: 148 rows x 16)
+    for (int i = tid; i < kStK * 16; i += 256) {
+        const int k = i >> 4, n4 = i & 15;
+        *reinterpret_cast<float4 *>(s_w + k * kStLDW + 4 * n4) = *reinterpret_cast<const float4 *>(a.w + k * 64 + 4 * n4);
+    }
+    // ---- input patch -> LDS: rows 2 r0 - 3 .. + 12, floats (2 c0 - 3) * 3 .. + 398 of each row, zero outside
+    const float *xb = a.x + (size_t)b * a.H * a.W * 3;
+    const int e0 = (2 * c0 - 3) * 3, row_f = a.W * 3;
+    constexpr int NIT = (kStPR * kStPS + 255) / 256;                  // 21 dwords per thread, all requested first
+    float pv[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        int i = tid + 256 * u;
+        i = i < kStPR * kStPS ? i : kStPR * kStPS - 1;
+        const int pr = i / kStPS, e = i - pr * kStPS;
+        const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+        const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
+        pv[u] = xb[(size_t)yc * row_f + xc];                          // clamped, unconditional
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = tid + 256 * u;
+        const int pr = i / kStPS, e = i - pr * kStPS;
+        const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+        const bool in = e < kStPCF && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+        if (i < kStPR * kStPS) s_x[i] = in ? pv[u] : 0.0f;
+    }
+    __syncthreads();
+
+    const int px = lane & 15, kq = lane >> 4;
+    // this wavefront: output row r0 + wv; tile mt = columns c0 + 16 mt + px
+    const float *xrow = s_x + (2 * wv) * kStPS + (2 * px) * 3;
+    const float *wl = s_w + px;
+    f32x4s acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mt][nb] = f32x4s{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < kStK / 4; ++s) {
+        // k = 4 s + kq -> (ky, position inside the kernel row); the four lanes groups of a step
+        // straddle at most one row boundary
+        const int ky0 = (4 * s) / 21;
+        int k = 4 * s + kq;
+        k = k > 146 ? 146 : k;                                        // the padded k = 147: any valid address, its weight is zero
+        const int ky = (k >= 21 * (ky0 + 1)) ? ky0 + 1 : ky0;
+        const int off = ky * kStPS + (k - 21 * ky);
+        float wf[4], xv[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) wf[nb] = wl[(4 * s + kq) * kStLDW + 16 * nb];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xv[mt] = xrow[off + 96 * mt];            // 16 pixels * 2 * 3 floats
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xv[mt], acc[mt][nb], 0, 0, 0);
+        // (fully unrolled, the scheduler would hoist all 296 LDS reads and spill)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int row = r0 + wv;
+    if (row >= a.Ho) return;
+    float *yr = a.y + ((size_t)b * a.Ho + row) * a.Wo * 64 + 4 * kq;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int col = c0 + 16 * mt + px;
+        if (col < a.Wo) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                *reinterpret_cast<f32x4s *>(yr + (size_t)col * 64 + 16 * nb) = acc[mt][nb];
+        }
+    }
+}
+
+}  // namespace ia
+
+extern "C" int ia_stem_conv7x7s2(const float *x, const float *w_packed, float *y, int B, int H, int W,
+                                 void *stream)
+{
+    if (!x || !w_packed || !y || B < 1 || H < 1 || W < 1) return IA_E_ARG;
+    if (((uintptr_t)w_packed & 15u) || ((uintptr_t)y & 15u) || ((uintptr_t)x & 3u)) return IA_E_ARG;
+    ia::StemArgs a;
+    a.x = x; a.w = w_packed; a.y = y; a.B = B; a.H = H; a.W = W;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.tiles_x = (a.Wo + ia::kStTC - 1) / ia::kStTC; a.tiles_y = (a.Ho + ia::kStTR - 1) / ia::kStTR;
+    const int64_t wgs = (int64_t)B * a.tiles_x * a.tiles_y;
+    if (wgs > 2147483647LL || (int64_t)W * 3 > 2147483647LL) return IA_E_ARG;
+    hipLaunchKernelGGL(ia::k_stem_conv7x7s2, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}

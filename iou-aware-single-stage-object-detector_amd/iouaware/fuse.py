@@ -257,7 +257,11 @@ def _resnet_forward(self, x):
 
 def _resnet_stem(self, x):
     f = self._ia_fused
-    x = self.conv1(x)
+    if 'stem_w' in f and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        x = ops.stem_conv(x, f['stem_w'])         # own fp32 MFMA kernel (csrc/stem.hip), raw convolution
+    else:
+        x = self.conv1(x)
     mp = self.maxpool
     if f.get('pool') and x.dtype in _VEC and x.shape[1] % _VEC[x.dtype] == 0 \
             and x.is_contiguous(memory_format=torch.channels_last):
@@ -467,6 +471,11 @@ def _fold(m):
         mp = m.maxpool
         f['pool'] = (_pair(mp.kernel_size), _pair(mp.stride), _pair(mp.padding),
                      _pair(mp.dilation), mp.ceil_mode) == ((3, 3), (2, 2), (1, 1), (1, 1), False)
+        c1 = m.conv1
+        if winograd and isinstance(c1, torch.nn.Conv2d) and tuple(c1.weight.shape) == (64, 3, 7, 7) \
+                and tuple(c1.stride) == (2, 2) and tuple(c1.padding) == (3, 3) and tuple(c1.dilation) == (1, 1) \
+                and c1.groups == 1 and c1.bias is None and getattr(c1, 'padding_mode', 'zeros') == 'zeros':
+            f['stem_w'] = ops.stem_weight(c1.weight)
         m._ia_fused = f
     elif isinstance(m, ConvModule):
         f = {}

@@ -695,6 +695,30 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
     return out
 
 
+def stem_weight(weight):
+    """(64, 3, 7, 7) stem weight -> the (148, 64) fp32 matrix of ia_stem_conv7x7s2
+    (row ky * 21 + kx * 3 + c, one zero row of K padding)"""
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise ValueError('the stem kernel covers a (64, 3, 7, 7) weight')
+    w = weight.detach().float().permute(2, 3, 1, 0).reshape(147, 64)
+    return torch.cat([w, torch.zeros(1, 64, dtype=torch.float32, device=w.device)], 0).contiguous()
+
+
+def stem_conv(x, w_packed):
+    """7x7 / stride 2 / pad 3 convolution 3 -> 64 of a channels-last fp32 image batch on the fp32
+    MFMA kernel of csrc/stem.hip -> the raw convolution, channels-last (B, 64, Ho, Wo)"""
+    _require_gpu(x, 'x')
+    B, C, H, W = x.shape
+    if C != 3 or x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last) \
+            or tuple(w_packed.shape) != (148, 64) or w_packed.dtype != torch.float32 or not w_packed.is_contiguous():
+        raise TypeError('stem_conv: channels-last fp32 (B, 3, H, W) input, packed (148, 64) weight')
+    y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    _lib.check(_lib.lib().ia_stem_conv7x7s2(_ptr(x), _ptr(w_packed), _ptr(y), B, H, W, _stream()),
+               'ia_stem_conv7x7s2')
+    return y
+
+
 def conv1x1_chain(x, w_kn, bias, residual, w2_kn, bias2):
     """the boundary between two stage-1 bottlenecks in one pass (csrc/conv1x1_stream.hip,
     k_conv1x1_chain): y = relu(x . w_kn + bias + residual), h = relu(y . w2_kn + bias2) computed from

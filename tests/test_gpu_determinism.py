@@ -129,8 +129,8 @@ def test_conv1x1_strided_matches_fp64_convolution(B, k, H, W, n, stride, dtype):
 
 
 def test_strided_routes_are_taken():
-    """fuse_inference(winograd=True): no strided convolution of R-50 is left on the library
-    convolution except the stem"""
+    """fuse_inference(winograd=True): no convolution of R-50 is left on the library convolution
+    (the stem runs on csrc/stem.hip since round 4)"""
     import bench
     m = bench.build_model(torch.device('cuda', 0), fuse=True, channels_last=True)
     firsts = [getattr(m.backbone, n)[0] for n in m.backbone.res_layers[1:]]
@@ -149,4 +149,4 @@ def test_strided_routes_are_taken():
             m.forward_head(x)
     finally:
         F.conv2d = orig
-    assert calls == [(64, 3, 7, 7)], calls        # the stem alone
+    assert calls == [], calls

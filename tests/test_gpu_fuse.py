@@ -287,3 +287,47 @@ def test_stage1_chained_boundaries_equal_unchained():
     assert len(small) == 4
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 37, 53), (2, 256, 320), (1, 7, 9), (2, 130, 515), (1, 800, 1344)])
+def test_stem_conv_matches_fp64(B, H, W):
+    """the 7x7 / stride-2 stem convolution on the fp32 MFMA kernel (csrc/stem.hip) against an fp64
+    convolution: odd sizes, maps smaller than a workgroup tile, partial tiles in both directions,
+    the benchmark's size"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(H * W)
+    x = torch.randn(B, 3, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 3, 7, 7, device='cuda', generator=g) * 0.1
+    y = ops.stem_conv(x, ops.stem_weight(w))
+    # fp64 reference as unfold + matmul (the library's fp64 convolution takes minutes at these sizes)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    cols = torch.nn.functional.unfold(x.double().contiguous(), 7, padding=3, stride=2)        # (B, 147, Ho * Wo)
+    want = torch.matmul(w.double().reshape(64, 147), cols).reshape(B, 64, Ho, Wo)
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+def test_fused_stem_takes_the_own_kernel_and_matches_the_modules():
+    """fuse_inference(winograd=True): ResNet._stem = own convolution kernel + the fused BN / ReLU /
+    max-pool pass; against conv1 -> norm1 -> relu -> maxpool of the plain modules"""
+    from iouaware import ops
+    from iouaware.backbones import ResNet
+    from iouaware.fuse import fuse_inference
+    torch.manual_seed(5)
+    net = ResNet(depth=50, num_stages=1, strides=(1,), dilations=(1,), out_indices=(0,)).cuda().eval()
+    net.norm1.running_mean.normal_(0, 0.1); net.norm1.running_var.uniform_(0.5, 1.5)
+    net.norm1.weight.data.uniform_(0.5, 1.5); net.norm1.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 3, 203, 311, device='cuda').contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = net.maxpool(net.relu(net.norm1(net.conv1(x))))
+        fuse_inference(net, winograd=True)
+        assert 'stem_w' in net._ia_fused
+        calls = []
+        orig = ops.stem_conv
+        ops.stem_conv = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            got = net._stem(x)
+        finally:
+            ops.stem_conv = orig
+    assert calls == [1]
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
