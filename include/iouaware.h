@@ -665,6 +665,10 @@ int ia_conv1x1_stream(const float *x, const float *w, const float *bias, const f
 int ia_conv1x1_chain(const float *x, const float *w, const float *bias, const float *residual,
                      const float *w2, const float *bias2, float *y, float *h, int64_t rows, int k,
                      int n, int n2, void *stream);
+/* The same streaming product for a wide output row: (k, n) = (128, 512), column blocks of 256
+ * channels per workgroup (ResNet stage 2: conv3 + bn3 + identity + ReLU, resnet.py:215-255).   */
+int ia_conv1x1_wide(const float *x, const float *w, const float *bias, const float *residual,
+                    float *y, int64_t rows, int k, int n, int relu, void *stream);
 
 /* ------------------------------------------------------------------ bf16 3x3 convolution
  * 3x3 / stride 1 / pad 1 convolution + bias (+ReLU) on bf16 channels-last tensors, fp32

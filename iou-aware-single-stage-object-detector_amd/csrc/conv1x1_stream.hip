@@ -101,6 +101,86 @@ __global__ void __launch_bounds__(kC1Threads) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// The same streaming product for a WIDE output: y[:, n0 : n0 + NT] = relu?(x . W[:, n0 : n0 + NT] + bias
+// + residual) with the output row wider than one workgroup's column block (ResNet stage 2: conv3 of a
+// bottleneck, 128 -> 512 with the residual, 134 400 pixels at batch 8: 619 MB for 17.6 GFLOP; the
+// library GEMM 203 us = 3.0 TB/s).  Grid rows = column blocks of NT = 256 channels; a block's K x NT
+// weights (128 x 256: 133 KB with the bank padding) sit in LDS: one workgroup of 16 wavefronts per CU.
+// x is read once per column block (69 MB x 2: L2 / MALL-resident behind the first block).
+struct WideArgs {
+    const float *x, *w, *bias, *res;      // x (P, K), w (K, ldn), bias (ldn) or NULL, res (P, ldn) or NULL
+    float *y;                             // (P, ldn)
+    int64_t P;
+    int32_t relu, tiles, ldn;
+};
+
+constexpr int kWideThreads = 1024;
+
+template <int K, int NT>
+__global__ void __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_conv1x1_wide(WideArgs a)
+{
+    constexpr int NB = NT / 16, J = K / 16, LDW = NT + 4;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float *s_w = s_dyn, *s_bias = s_w + K * LDW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n0 = blockIdx.y * NT;
+    for (int i = tid; i < K * (NT / 4); i += kWideThreads) {
+        const int k = i / (NT / 4), n4 = i - k * (NT / 4);
+        *reinterpret_cast<float4 *>(s_w + k * LDW + 4 * n4) = *reinterpret_cast<const float4 *>(a.w + (size_t)k * a.ldn + n0 + 4 * n4);
+    }
+    for (int i = tid; i < NT; i += kWideThreads) s_bias[i] = a.bias ? a.bias[n0 + i] : 0.0f;
+    __syncthreads();
+
+    const int p_in = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * (kWideThreads / 64) + (tid >> 6), nwaves = gridDim.x * (kWideThreads / 64);
+    const float *wq = s_w + (4 * q) * LDW + p_in;
+    for (int tile = wave; tile < a.tiles; tile += nwaves) {
+        const int64_t p0 = (int64_t)tile * 16 + p_in;
+        const int64_t p = p0 < a.P ? p0 : a.P - 1;         // clamped: loads unconditional
+        const float *xr = a.x + p * K + 4 * q;
+        f32x4 xv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4 *>(xr + 16 * j);
+        f32x4 acc[NB];
+        if (a.res) {
+            const float *rr = a.res + p * a.ldn + n0 + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rr + 16 * nb));
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 bz = *reinterpret_cast<const f32x4 *>(s_bias + 16 * nb + 4 * q);
+            acc[nb] += bz;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xb = xv[j][c];
+                const float *wrow = wq + (16 * j + c) * LDW;
+                float wf[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[nb] = wrow[16 * nb];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (p0 < a.P) {
+            float *yr = a.y + p * a.ldn + n0 + 4 * q;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 v = acc[nb];
+                if (a.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                *reinterpret_cast<f32x4 *>(yr + 16 * nb) = v;
+            }
+        }
+    }
+}
+
 // Two products per pixel tile (ResNet stage 1, the boundary between two bottlenecks, reference
 // resnet.py:215-255): y = relu(x . W + bias + residual) (64 -> 256, the block's conv3 + bn3 + add +
 // ReLU) is stored AND fed, still in the accumulators, into the next block's conv1 + bn1 + ReLU
@@ -303,5 +383,39 @@ extern "C" int ia_batched_gemm_stream(const float *A, const float *W, float *D, 
     else if (k == 128 && n == 128) hipLaunchKernelGGL((ia::k_conv1x1_stream<128, 128>), grid, block, 0, s, a);
     else if (k == 256 && n == 48) hipLaunchKernelGGL((ia::k_conv1x1_stream<256, 48>), grid, block, 0, s, a);
     else return IA_E_ARG;
+    return ia::hip_status(hipGetLastError());
+}
+
+/* y = relu?(x . w + bias (+ residual)) for (k, n) = (128, 512) on k_conv1x1_wide (column blocks of 256) */
+extern "C" int ia_conv1x1_wide(const float *x, const float *w, const float *bias, const float *residual,
+                               float *y, int64_t rows, int k, int n, int relu, void *stream)
+{
+    if (!x || !w || !y || rows < 1) return IA_E_ARG;
+    if (((uintptr_t)x & 15u) || ((uintptr_t)w & 15u) || ((uintptr_t)y & 15u) || ((uintptr_t)residual & 15u)) return IA_E_ARG;
+    if (k != 128 || n != 512) return IA_E_ARG;
+    ia::WideArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y; a.P = rows; a.relu = relu ? 1 : 0; a.ldn = n;
+    const int64_t tiles = (rows + 15) / 16;
+    if (tiles > 2147483647LL) return IA_E_ARG;
+    a.tiles = (int32_t)tiles;
+    int64_t wgs = (tiles + 15) / 16;
+    if (wgs > 128) wgs = 128;                              // x 2 column blocks = one resident workgroup per CU
+    const size_t lds = sizeof(float) * (128 * (256 + 4) + 256);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return IA_E_ARG;
+    {
+        static std::mutex mu;
+        static std::vector<char> done;
+        std::lock_guard<std::mutex> lock(mu);
+        if ((size_t)dev >= done.size()) done.resize((size_t)dev + 1, 0);
+        if (!done[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ia::k_conv1x1_wide<128, 256>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return ia::hip_status(e);
+            done[dev] = 1;
+        }
+    }
+    hipLaunchKernelGGL((ia::k_conv1x1_wide<128, 256>), dim3((unsigned)wgs, 2), dim3(ia::kWideThreads), lds,
+                       (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }

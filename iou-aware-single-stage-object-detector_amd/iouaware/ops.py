@@ -671,6 +671,13 @@ def linear_bias_act(x, w_kn, bias=None, residual=None, relu=False, w_nk=False):
         raise ValueError('residual must be a channels-last tensor of the output shape')
     if residual is not None and residual.dtype != x.dtype:
         raise TypeError('residual dtype mismatch')
+    if x.dtype == torch.float32 and not w_nk and WIDE_1X1 and (k, n) == (128, 512) and residual is not None \
+            and B * H * W >= 65536:
+        # ResNet stage 2 tail: HBM-bound (619 MB for 17.6 GFLOP at batch 8) -> the streaming kernel's
+        # wide-output form, column blocks of 256 channels (csrc/conv1x1_stream.hip, k_conv1x1_wide)
+        _lib.check(_lib.lib().ia_conv1x1_wide(_ptr(x), _ptr(w_kn), _ptr(bias), _ptr(residual), _ptr(out),
+                                              B * H * W, k, n, int(bool(relu)), _stream()), 'ia_conv1x1_wide')
+        return out
     if x.dtype == torch.float32 and not w_nk and STREAM_1X1 and (k, n) in _STREAM_SHAPES \
             and B * H * W >= 65536:
         # ResNet stage 1: HBM-bound products with 16 K weights -> the streaming kernel with the
@@ -838,6 +845,7 @@ def conv1x1_strided(x, w_kn, bias=None, residual=None, stride=2, relu=False):
 
 _STREAM_SHAPES = ((64, 256), (256, 64), (64, 64))
 STREAM_1X1 = True                      # linear_bias_act routes these shapes to conv1x1_stream
+WIDE_1X1 = True                        # ... and (128, 512) + residual to ia_conv1x1_wide
 
 
 def conv1x1_stream(x, w_kn, bias=None, residual=None, relu=False):

@@ -331,3 +331,24 @@ def test_fused_stem_takes_the_own_kernel_and_matches_the_modules():
             ops.stem_conv = orig
     assert calls == [1]
     assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+def test_conv1x1_wide_matches_fp64_and_library():
+    """the stage-2 tail (128 -> 512 + residual + ReLU) on the streaming kernel's wide-output form
+    (column blocks of 256 channels) against fp64 and the library GEMM it replaces; rows % 16 != 0"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn(2, 128, 190, 173, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)   # 65 740 pixels
+    w = torch.randn(128, 512, device='cuda', generator=g) * 0.08
+    b = torch.randn(512, device='cuda', generator=g)
+    r = torch.randn(2, 512, 190, 173, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    got = ops.linear_bias_act(x, w, b, residual=r, relu=True)            # routed to ia_conv1x1_wide
+    ops.WIDE_1X1 = False
+    try:
+        lib = ops.linear_bias_act(x, w, b, residual=r, relu=True)
+    finally:
+        ops.WIDE_1X1 = True
+    want = (torch.einsum('bkhw,kn->bnhw', x.double(), w.double()) + b.double().view(1, -1, 1, 1) + r.double()).clamp(min=0)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert float((got - lib).abs().max()) < 1e-5 * float(lib.abs().max())

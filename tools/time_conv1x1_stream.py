@@ -46,3 +46,15 @@ t0, t1 = bench(two), bench(lambda: ops.conv1x1_chain(x, w, b, r, w2, b2))
 mb = (x.numel() + r.numel() + y0.numel() + h0.numel()) * 4 / 1e6
 print('boundary 64 -> 256 (+res) -> 64: two kernels %.1f us, chained %.1f us (%.0f MB, %.2f TB/s); same bits: %s'
       % (t0 * 1e3, t1 * 1e3, mb, mb / t1 / 1e3, torch.equal(y0, y1) and torch.equal(h0, h1)), flush=True)
+
+# stage-2 tail: 128 -> 512 + residual + ReLU at 100 x 168 (k_conv1x1_wide) against the library GEMM
+x = torch.randn(B, 128, 100, 168, device='cuda').contiguous(memory_format=cl)
+w = torch.randn(128, 512, device='cuda') * 0.05
+b = torch.randn(512, device='cuda')
+r = torch.randn(B, 512, 100, 168, device='cuda').contiguous(memory_format=cl)
+ops.WIDE_1X1 = False
+t0 = bench(lambda: ops.linear_bias_act(x, w, b, residual=r, relu=True))
+ops.WIDE_1X1 = True
+t1 = bench(lambda: ops.linear_bias_act(x, w, b, residual=r, relu=True))
+mb = (x.numel() + 2 * r.numel()) * 4 / 1e6
+print('128 -> 512 res=1  %.0f MB  library %.1f us (%.2f TB/s)   own (wide) %.1f us (%.2f TB/s)' % (mb, t0 * 1e3, mb / t0 / 1e3, t1 * 1e3, mb / t1 / 1e3), flush=True)
