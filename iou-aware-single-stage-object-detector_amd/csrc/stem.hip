@@ -132,7 +132,139 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }   // tiles of this workgroup
 }
 
+// ---- bf16 (BASELINE config 3): the same convolution on v_mfma_f32_16x16x16_bf16.  K = 7 kernel rows x 24
+// (21 values + 3 of zero weight: groups of four consecutive k never straddle a kernel row), 11 steps
+// of 16.  The weights live in REGISTERS (11 x 4 fragments x 8 bytes per lane = 88 VGPRs, loaded once
+// per wavefront from a fragment-order packing); the 13 x 133-pixel patch sits in LDS as bf16 and a
+// lane reads its four consecutive k as two aligned dwords (byte offset 12 px + 2 r, r % 4 == 0).
+typedef short v4s __attribute__((ext_vector_type(4)));
+constexpr int kSbPitch = 404;                        // bf16 elements per patch row (399 + over-read of the padded k)
+constexpr int kSbSteps = 11;
+
+struct StemBfArgs {
+    const uint16_t *x;       // (B, H, W, 3) bf16
+    const uint16_t *w;       // [11 steps][4 blocks][64 lanes][4] bf16, fragment order
+    uint16_t *y;             // (B, Ho, Wo, 64) bf16
+    int32_t B, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
+};
+
+__device__ __forceinline__ uint32_t stem_bf16_rne(float f)
+{
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stem_conv7x7s2_bf16(StemBfArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_x[kStPR * kSbPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 15, kq = lane >> 4;
+    // weight fragments: wfr[s][nb] = W[nb * 16 + px][16 s + 4 kq .. + 3]
+    v4s wfr[kSbSteps][4];
+#pragma unroll
+    for (int s = 0; s < kSbSteps; ++s)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            wfr[s][nb] = *reinterpret_cast<const v4s *>(a.w + ((size_t)(s * 4 + nb) * 64 + lane) * 4);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int txi = t % a.tiles_x; t /= a.tiles_x;
+        const int tyi = t % a.tiles_y;
+        const int b = t / a.tiles_y;
+        const int r0 = tyi * kStTR, c0 = txi * kStTC;
+        __syncthreads();                                  // the previous tile's reads of s_x are done
+        const uint16_t *xb = a.x + (size_t)b * a.H * a.W * 3;
+        const int e0 = (2 * c0 - 3) * 3, row_f = a.W * 3;
+        constexpr int NIT = (kStPR * kSbPitch + 255) / 256;               // 21 values per thread, all requested first
+        uint16_t pv[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            int i = tid + 256 * u;
+            i = i < kStPR * kSbPitch ? i : kStPR * kSbPitch - 1;
+            const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+            const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
+            pv[u] = xb[(size_t)yc * row_f + xc];                          // clamped, unconditional
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+            const bool in = e < kStPCF && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+            if (i < kStPR * kSbPitch) s_x[i] = in ? pv[u] : (uint16_t)0;
+        }
+        __syncthreads();
+
+        // this wavefront: output row r0 + wv; tile mt = columns c0 + 16 mt + px
+        const unsigned char *xrow = reinterpret_cast<const unsigned char *>(s_x) + ((2 * wv) * kSbPitch + 6 * px) * 2;
+        f32x4s acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mt][nb] = f32x4s{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < kSbSteps; ++s) {
+            // k = 16 s + 4 kq .. + 3 -> (kernel row, position in the row of 24)
+            const int ky0 = (16 * s) / 24;
+            int k = 16 * s + 4 * kq;
+            k = k > 164 ? 164 : k;                         // the padded k >= 168: any valid address, zero weights
+            const int ky = (k >= 24 * (ky0 + 1)) ? ky0 + 1 : ky0;
+            const int off = (ky * kSbPitch + (k - 24 * ky)) * 2;            // bytes, a multiple of 8
+            v4s xf[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(xrow + off + 192 * mt);
+                const uint32_t hi = *reinterpret_cast<const uint32_t *>(xrow + off + 192 * mt + 4);
+                xf[mt] = __builtin_bit_cast(v4s, make_uint2(lo, hi));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfr[s][nb], xf[mt], acc[mt][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);            // (the LDS reads of later steps stay behind: spills otherwise)
+        }
+        const int row = r0 + wv;
+        if (row < a.Ho) {
+            uint16_t *yr = a.y + ((size_t)b * a.Ho + row) * a.Wo * 64 + 4 * kq;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int col = c0 + 16 * mt + px;
+                if (col < a.Wo) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const f32x4s v = acc[mt][nb];
+                        const uint32_t lo = stem_bf16_rne(v.x) | (stem_bf16_rne(v.y) << 16);
+                        const uint32_t hi = stem_bf16_rne(v.z) | (stem_bf16_rne(v.w) << 16);
+                        *reinterpret_cast<uint2 *>(yr + (size_t)col * 64 + 16 * nb) = make_uint2(lo, hi);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ia
+
+extern "C" int ia_stem_conv7x7s2_bf16(const void *x, const void *w_packed, void *y, int B, int H, int W,
+                                      void *stream)
+{
+    if (!x || !w_packed || !y || B < 1 || H < 1 || W < 1) return IA_E_ARG;
+    if (((uintptr_t)w_packed & 7u) || ((uintptr_t)y & 7u) || ((uintptr_t)x & 1u)) return IA_E_ARG;
+    ia::StemBfArgs a;
+    a.x = static_cast<const uint16_t *>(x); a.w = static_cast<const uint16_t *>(w_packed); a.y = static_cast<uint16_t *>(y);
+    a.B = B; a.H = H; a.W = W;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.tiles_x = (a.Wo + ia::kStTC - 1) / ia::kStTC; a.tiles_y = (a.Ho + ia::kStTR - 1) / ia::kStTR;
+    const int64_t tiles = (int64_t)B * a.tiles_x * a.tiles_y;
+    if (tiles > 2147483647LL || (int64_t)W * 3 > 2147483647LL) return IA_E_ARG;
+    a.ntiles = (int32_t)tiles;
+    const int64_t wgs = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL(ia::k_stem_conv7x7s2_bf16, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return ia::hip_status(hipGetLastError());
+}
 
 extern "C" int ia_stem_conv7x7s2(const float *x, const float *w_packed, float *y, int B, int H, int W,
                                  void *stream)

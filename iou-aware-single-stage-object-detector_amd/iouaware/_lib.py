@@ -182,6 +182,7 @@ SIGNATURES = {
     'ia_upsample2x_add_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ia_conv1x1_stream': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp]),
     'ia_stem_conv7x7s2': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'ia_stem_conv7x7s2_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'ia_conv1x1_wide': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp]),
     'ia_conv1x1_chain': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'ia_conv3x3_bf16_packed_bytes': (C.c_size_t, [_i, _i, _i]),

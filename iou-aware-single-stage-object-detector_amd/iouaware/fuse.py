@@ -260,6 +260,12 @@ def _resnet_stem(self, x):
     if 'stem_w' in f and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 \
             and x.is_contiguous(memory_format=torch.channels_last):
         x = ops.stem_conv(x, f['stem_w'])         # own fp32 MFMA kernel (csrc/stem.hip), raw convolution
+    elif 'stem_w' in f and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        w16 = f.get('_stem_w16')
+        if w16 is None:
+            w16 = f['_stem_w16'] = ops.stem_weight_bf16(self.conv1.weight)
+        x = ops.stem_conv_bf16(x, w16)            # bf16 MFMA variant
     else:
         x = self.conv1(x)
     mp = self.maxpool

@@ -726,6 +726,35 @@ def stem_conv(x, w_packed):
     return y
 
 
+def stem_weight_bf16(weight):
+    """(64, 3, 7, 7) stem weight -> the fragment-order bf16 packing of ia_stem_conv7x7s2_bf16:
+    [step 11][block 4][lane 64][4], k = ky * 24 + kx * 3 + c padded with zeros"""
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise ValueError('the stem kernel covers a (64, 3, 7, 7) weight')
+    w = weight.detach().float()
+    wk = torch.zeros((64, 8, 8, 3), dtype=torch.float32, device=w.device)        # (n, ky, kx, c), ky / kx padded to 8
+    wk[:, :7, :7, :] = w.permute(0, 2, 3, 1)
+    wk = wk.reshape(64, 8 * 24)[:, :176]                                          # k = ky * 24 + kx * 3 + c, 11 steps of 16
+    # [n = nb * 16 + m][k = 16 s + 4 q + e] -> [s][nb][lane = q * 16 + m][e]
+    wk = wk.reshape(4, 16, 11, 4, 4).permute(2, 0, 3, 1, 4).contiguous()        # (s, nb, q, m, e)
+    return wk.reshape(11, 4, 64, 4).to(torch.bfloat16).contiguous()
+
+
+def stem_conv_bf16(x, w_packed):
+    """the stem convolution of a channels-last bf16 image batch (csrc/stem.hip, bf16 MFMA) -> the raw
+    convolution, channels-last bf16 (B, 64, Ho, Wo)"""
+    _require_gpu(x, 'x')
+    B, C, H, W = x.shape
+    if C != 3 or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last) \
+            or tuple(w_packed.shape) != (11, 4, 64, 4) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
+        raise TypeError('stem_conv_bf16: channels-last bf16 (B, 3, H, W) input, packed (11, 4, 64, 4) weight')
+    y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    _lib.check(_lib.lib().ia_stem_conv7x7s2_bf16(_ptr(x), _ptr(w_packed), _ptr(y), B, H, W, _stream()),
+               'ia_stem_conv7x7s2_bf16')
+    return y
+
+
 def conv1x1_chain(x, w_kn, bias, residual, w2_kn, bias2):
     """the boundary between two stage-1 bottlenecks in one pass (csrc/conv1x1_stream.hip,
     k_conv1x1_chain): y = relu(x . w_kn + bias + residual), h = relu(y . w2_kn + bias2) computed from

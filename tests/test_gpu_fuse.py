@@ -352,3 +352,21 @@ def test_conv1x1_wide_matches_fp64_and_library():
     assert got.is_contiguous(memory_format=torch.channels_last)
     assert float((got.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
     assert float((got - lib).abs().max()) < 1e-5 * float(lib.abs().max())
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 37, 53), (2, 256, 320), (1, 7, 9), (1, 130, 515)])
+def test_stem_conv_bf16_matches_fp64_of_the_rounded_operands(B, H, W):
+    """the bf16 stem kernel (v_mfma_f32_16x16x16_bf16, weights in registers) against an fp64
+    convolution of the bf16-rounded operands: fp32 accumulation, one rounding of the result"""
+    from iouaware import ops
+    g = torch.Generator(device='cuda').manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+    y = ops.stem_conv_bf16(x, ops.stem_weight_bf16(w))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    cols = torch.nn.functional.unfold(x.double().contiguous(), 7, padding=3, stride=2)
+    want = torch.matmul(w.double().reshape(64, 147), cols).reshape(B, 64, Ho, Wo)
+    assert y.shape == want.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.double() - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())
+    assert bool((err <= tol).all()), (float(err.max()), float(want.abs().max()))

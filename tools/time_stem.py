@@ -22,3 +22,11 @@ for B in (8, 1):
     err = float((ops.stem_conv(x, wp) - F.conv2d(x, w, None, 2, 3)).abs().max())
     print('B=%d  library %.3f ms (%.0f TF)   own %.3f ms (%.0f TF, %.2f TB/s written)   max diff %.2e'
           % (B, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, B * 400 * 672 * 64 * 4 / t1 / 1e9, err), flush=True)
+
+# bf16 (config 3): batch 16
+x = torch.randn(16, 3, 800, 1344, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+w = (torch.randn(64, 3, 7, 7, device='cuda') * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+wp = ops.stem_weight_bf16(w)
+t0 = bench(lambda: F.conv2d(x, w, None, 2, 3))
+t1 = bench(lambda: ops.stem_conv_bf16(x, wp))
+print('bf16 B=16  library %.3f ms   own %.3f ms (%.2f TB/s written)' % (t0, t1, 16 * 400 * 672 * 64 * 2 / t1 / 1e9), flush=True)
