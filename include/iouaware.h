@@ -655,7 +655,7 @@ int ia_stem_conv7x7s2(const float *x, const float *w_packed, float *y, int B, in
 /* The same convolution on bf16 (BASELINE config 3) on v_mfma_f32_16x16x16_bf16: x (B, H, W, 3) bf16,
  * y (B, Ho, Wo, 64) bf16 (fp32 accumulation, one rounding), w_packed = 11 x 4 x 64 x 4 bf16 in
  * fragment order: element [s][nb][lane][e] = w[nb * 16 + (lane & 15)][k = 16 s + 4 (lane >> 4) + e]
- * with k = ky * 24 + kx * 3 + c (zero for kx = 7 and ky = 7).                                    */
+ * with k = ky * 24 + 1 + kx * 3 + c (zero at the other positions and for ky = 7).                                    */
 int ia_stem_conv7x7s2_bf16(const void *x, const void *w_packed, void *y, int B, int H, int W,
                            void *stream);
 

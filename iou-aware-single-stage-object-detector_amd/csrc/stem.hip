@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ---- bf16 (BASELINE config 3): the same convolution on v_mfma_f32_16x16x16_bf16.  K = 7 kernel rows x 24
-// (21 values + 3 of zero weight: groups of four consecutive k never straddle a kernel row), 11 steps
+// (one zero, 21 values, two zeros: groups of four consecutive k never straddle a kernel row), 11 steps
 // of 16.  The weights live in REGISTERS (11 x 4 fragments x 8 bytes per lane = 88 VGPRs, loaded once
 // per wavefront from a fragment-order packing); the 13 x 133-pixel patch sits in LDS as bf16 and a
 // lane reads its four consecutive k as two aligned dwords (byte offset 12 px + 2 r, r % 4 == 0).
@@ -155,6 +155,12 @@ __device__ __forceinline__ uint32_t stem_bf16_rne(float f)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// AL: the image rows are 4-byte aligned (W even): the patch is staged with aligned DWORD copies.  The
+// first element a tile needs, (2 c0 - 3) * 3, is odd, so the LDS row starts ONE ELEMENT EARLIER
+// (LDS[i] = row[e0 - 1 + i], e0 - 1 even) and the K grouping is shifted by one to keep the lanes'
+// four-element reads dword-aligned in LDS: a kernel row is [zero, 21 values, zero, zero], i.e.
+// k' = 1 + kx * 3 + c (see ops.stem_weight_bf16).  Odd W: the same LDS content through 2-byte loads.
+template <bool AL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stem_conv7x7s2_bf16(StemBfArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_x[kStPR * kSbPitch];
@@ -175,25 +181,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int r0 = tyi * kStTR, c0 = txi * kStTC;
         __syncthreads();                                  // the previous tile's reads of s_x are done
         const uint16_t *xb = a.x + (size_t)b * a.H * a.W * 3;
-        const int e0 = (2 * c0 - 3) * 3, row_f = a.W * 3;
-        constexpr int NIT = (kStPR * kSbPitch + 255) / 256;               // 21 values per thread, all requested first
-        uint16_t pv[NIT];
+        const int e0 = (2 * c0 - 3) * 3 - 1, row_f = a.W * 3;            // first element of the LDS row (even)
+        if (AL) {
+            constexpr int ND = kStPR * (kSbPitch / 2);                    // 13 x 202 dwords
+            constexpr int NIT = (ND + 255) / 256;                         // 11 per thread, all requested first
+            uint32_t pv[NIT];
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            int i = tid + 256 * u;
-            i = i < kStPR * kSbPitch ? i : kStPR * kSbPitch - 1;
-            const int pr = i / kSbPitch, e = i - pr * kSbPitch;
-            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-            const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
-            pv[u] = xb[(size_t)yc * row_f + xc];                          // clamped, unconditional
-        }
+            for (int u = 0; u < NIT; ++u) {
+                int i = tid + 256 * u;
+                i = i < ND ? i : ND - 1;
+                const int pr = i / (kSbPitch / 2), e = 2 * (i - pr * (kSbPitch / 2));
+                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;              // even
+                const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 2 : xe);
+                pv[u] = *reinterpret_cast<const uint32_t *>(xb + (size_t)yc * row_f + xc);      // clamped, unconditional
+            }
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = tid + 256 * u;
-            const int pr = i / kSbPitch, e = i - pr * kSbPitch;
-            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-            const bool in = e < kStPCF && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
-            if (i < kStPR * kSbPitch) s_x[i] = in ? pv[u] : (uint16_t)0;
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                const int pr = i / (kSbPitch / 2), e = 2 * (i - pr * (kSbPitch / 2));
+                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+                // (row_f and xe are even: a dword is inside or outside the row as a whole)
+                const bool in = e < kStPCF + 1 && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+                if (i < ND) reinterpret_cast<uint32_t *>(s_x)[i] = in ? pv[u] : 0u;
+            }
+        } else {
+            constexpr int NIT = (kStPR * kSbPitch + 255) / 256;           // 21 values per thread, all requested first
+            uint16_t pv[NIT];
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                int i = tid + 256 * u;
+                i = i < kStPR * kSbPitch ? i : kStPR * kSbPitch - 1;
+                const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+                const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
+                pv[u] = xb[(size_t)yc * row_f + xc];                      // clamped, unconditional
+            }
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + 256 * u;
+                const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+                const bool in = e < kStPCF + 1 && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+                if (i < kStPR * kSbPitch) s_x[i] = in ? pv[u] : (uint16_t)0;
+            }
         }
         __syncthreads();
 
@@ -262,7 +292,10 @@ extern "C" int ia_stem_conv7x7s2_bf16(const void *x, const void *w_packed, void 
     if (tiles > 2147483647LL || (int64_t)W * 3 > 2147483647LL) return IA_E_ARG;
     a.ntiles = (int32_t)tiles;
     const int64_t wgs = tiles < 512 ? tiles : 512;
-    hipLaunchKernelGGL(ia::k_stem_conv7x7s2_bf16, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    if ((W & 1) == 0 && ((uintptr_t)x & 3u) == 0)
+        hipLaunchKernelGGL(ia::k_stem_conv7x7s2_bf16<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ia::k_stem_conv7x7s2_bf16<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
 

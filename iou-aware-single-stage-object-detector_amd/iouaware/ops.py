@@ -728,13 +728,13 @@ def stem_conv(x, w_packed):
 
 def stem_weight_bf16(weight):
     """(64, 3, 7, 7) stem weight -> the fragment-order bf16 packing of ia_stem_conv7x7s2_bf16:
-    [step 11][block 4][lane 64][4], k = ky * 24 + kx * 3 + c padded with zeros"""
+    [step 11][block 4][lane 64][4], k = ky * 24 + 1 + kx * 3 + c, zeros elsewhere"""
     if tuple(weight.shape) != (64, 3, 7, 7):
         raise ValueError('the stem kernel covers a (64, 3, 7, 7) weight')
     w = weight.detach().float()
-    wk = torch.zeros((64, 8, 8, 3), dtype=torch.float32, device=w.device)        # (n, ky, kx, c), ky / kx padded to 8
-    wk[:, :7, :7, :] = w.permute(0, 2, 3, 1)
-    wk = wk.reshape(64, 8 * 24)[:, :176]                                          # k = ky * 24 + kx * 3 + c, 11 steps of 16
+    wk = torch.zeros((64, 8, 24), dtype=torch.float32, device=w.device)          # (n, ky padded to 8, position in the row of 24)
+    wk[:, :7, 1:22] = w.permute(0, 2, 3, 1).reshape(64, 7, 21)                    # k = ky * 24 + 1 + kx * 3 + c (csrc/stem.hip)
+    wk = wk.reshape(64, 8 * 24)[:, :176]                                          # 11 steps of 16
     # [n = nb * 16 + m][k = 16 s + 4 q + e] -> [s][nb][lane = q * 16 + m][e]
     wk = wk.reshape(4, 16, 11, 4, 4).permute(2, 0, 3, 1, 4).contiguous()        # (s, nb, q, m, e)
     return wk.reshape(11, 4, 64, 4).to(torch.bfloat16).contiguous()
