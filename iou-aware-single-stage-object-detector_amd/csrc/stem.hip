@@ -33,9 +33,14 @@ struct StemArgs {
 constexpr int kStTR = 4, kStTC = 64;                 // output rows / columns per workgroup
 constexpr int kStPR = 2 * kStTR + 5;                 // 13 patch rows
 constexpr int kStPCF = (2 * kStTC + 5) * 3;          // 399 floats per patch row
-constexpr int kStPS = 400;                           // LDS pitch of a patch row (floats)
+constexpr int kStPS = 404;                           // LDS pitch of a patch row (floats): 3 lead-in + 399 + 2
+constexpr int kStLead = 3;                           // the LDS row starts 3 floats early: (2 c0 - 3) * 3 - 3 is a multiple of 4
 constexpr int kStK = 148, kStLDW = 80;               // K steps * 4; LDS pitch of a weight row
 
+// AL: image rows 16-byte aligned (W % 4 == 0): the patch is staged with float4 copies -- the LDS row
+// starts kStLead floats before the first one a tile needs, at a multiple of four floats of the image
+// row; the operand reads (4-byte LDS reads, any alignment) add the lead-in.  Other widths: dword copies.
+template <bool AL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_stem_conv7x7s2(StemArgs a)
 {
     __shared__ __attribute__((aligned(16))) float s_x[kStPR * kStPS];
@@ -57,30 +62,53 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();                                  // the previous tile's reads of s_x are done
     // ---- input patch -> LDS: rows 2 r0 - 3 .. + 12, floats (2 c0 - 3) * 3 .. + 398 of each row, zero outside
     const float *xb = a.x + (size_t)b * a.H * a.W * 3;
-    const int e0 = (2 * c0 - 3) * 3, row_f = a.W * 3;
-    constexpr int NIT = (kStPR * kStPS + 255) / 256;                  // 21 dwords per thread, all requested first
-    float pv[NIT];
+    const int e0 = (2 * c0 - 3) * 3 - kStLead, row_f = a.W * 3;      // first float of the LDS row (a multiple of 4)
+    if (AL) {
+        constexpr int NV = kStPR * (kStPS / 4);                       // 13 x 101 float4
+        constexpr int NIT = (NV + 255) / 256;                         // 6 per thread, all requested first
+        float4 pv[NIT];
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        int i = tid + 256 * u;
-        i = i < kStPR * kStPS ? i : kStPR * kStPS - 1;
-        const int pr = i / kStPS, e = i - pr * kStPS;
-        const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-        const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
-        pv[u] = xb[(size_t)yc * row_f + xc];                          // clamped, unconditional
-    }
+        for (int u = 0; u < NIT; ++u) {
+            int i = tid + 256 * u;
+            i = i < NV ? i : NV - 1;
+            const int pr = i / (kStPS / 4), e = 4 * (i - pr * (kStPS / 4));
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;              // a multiple of 4, like row_f
+            const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 4 : xe);
+            pv[u] = *reinterpret_cast<const float4 *>(xb + (size_t)yc * row_f + xc);          // clamped, unconditional
+        }
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        const int i = tid + 256 * u;
-        const int pr = i / kStPS, e = i - pr * kStPS;
-        const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-        const bool in = e < kStPCF && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
-        if (i < kStPR * kStPS) s_x[i] = in ? pv[u] : 0.0f;
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int pr = i / (kStPS / 4), e = 4 * (i - pr * (kStPS / 4));
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+            const bool in = yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;       // whole vectors: xe, row_f multiples of 4
+            if (i < NV) reinterpret_cast<float4 *>(s_x)[i] = in ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        constexpr int NIT = (kStPR * kStPS + 255) / 256;              // 21 dwords per thread, all requested first
+        float pv[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            int i = tid + 256 * u;
+            i = i < kStPR * kStPS ? i : kStPR * kStPS - 1;
+            const int pr = i / kStPS, e = i - pr * kStPS;
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+            const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
+            pv[u] = xb[(size_t)yc * row_f + xc];                      // clamped, unconditional
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u;
+            const int pr = i / kStPS, e = i - pr * kStPS;
+            const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+            const bool in = yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+            if (i < kStPR * kStPS) s_x[i] = in ? pv[u] : 0.0f;
+        }
     }
     __syncthreads();
 
     // this wavefront: output row r0 + wv; tile mt = columns c0 + 16 mt + px
-    const float *xrow = s_x + (2 * wv) * kStPS + (2 * px) * 3;
+    const float *xrow = s_x + (2 * wv) * kStPS + (2 * px) * 3 + kStLead;
     const float *wl = s_w + px;
     f32x4s acc[4][4];
 #pragma unroll
@@ -312,6 +340,9 @@ extern "C" int ia_stem_conv7x7s2(const float *x, const float *w_packed, float *y
     if (tiles > 2147483647LL || (int64_t)W * 3 > 2147483647LL) return IA_E_ARG;
     a.ntiles = (int32_t)tiles;
     const int64_t wgs = tiles < 512 ? tiles : 512;          // two resident workgroups per CU, tiles strided over them
-    hipLaunchKernelGGL(ia::k_stem_conv7x7s2, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    if ((W & 3) == 0 && ((uintptr_t)x & 15u) == 0)
+        hipLaunchKernelGGL(ia::k_stem_conv7x7s2<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ia::k_stem_conv7x7s2<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     return ia::hip_status(hipGetLastError());
 }
