@@ -114,18 +114,46 @@ def metas(batch):
 
 class Stepper(object):
     """one benchmark step = the product path: network forward + ops.get_bboxes (one fused C-ABI
-    call for the whole post-conv path) (+ the all-gather when N > 1).  No events, no stage-wise
-    launches inside the timed region; the roofline figures come from decode_stage_roofline()."""
+    call for the whole post-conv path) (+ the all-gather when N > 1).  No stage-wise launches
+    inside the timed region.  With `stage_events(n)` armed, each of the next n steps hands the
+    library a fresh pair of HIP events that ops.get_bboxes records on its stream in front of the
+    decode stage's first launch and behind its last one (ia_profile_stage_events): the stage timed
+    INSIDE the steps of the timed region (two event records per step, no synchronisation); the
+    back-to-back figures of decode_stage_roofline() stay beside it."""
 
     def __init__(self, model, imgs, world):
         self.model, self.imgs, self.world = model, imgs, world
         self.metas = metas(imgs.shape[0])
         self.cfg = model.test_cfg
         self.last = None
+        self.events, self.ev_next = [], 0
+
+    def stage_events(self, n, skip=0):
+        """arm n event pairs for the steps after the next `skip` ones (created by one record each:
+        torch makes the HIP event lazily)"""
+        self.events, self.ev_next = [], -skip
+        for _ in range(n):
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            pair[1].record()
+            self.events.append(pair)
+        torch.cuda.synchronize()
+
+    def stage_times_ms(self):
+        """-> the decode stage's duration in each step that used an event pair (call after a
+        device synchronisation); switches the hook off"""
+        ops.stage_events(None, None)
+        return [a.elapsed_time(b) for a, b in self.events[:max(0, min(self.ev_next, len(self.events)))]]
 
     @torch.no_grad()
     def step(self, timed=False):
         """one benchmark step = this rank's detections (+ the all-gather when N > 1)"""
+        if self.events and self.ev_next <= len(self.events):
+            if 0 <= self.ev_next < len(self.events):
+                ops.stage_events(*self.events[self.ev_next])
+            elif self.ev_next == len(self.events):
+                ops.stage_events(None, None)
+            self.ev_next += 1
         dets, labels, num, cls, reg, iou = self.local_detections(timed)
         if self.world > 1:
             dets, labels, num = idist.all_gather_detections(dets, labels, num)
@@ -901,7 +929,10 @@ def main():
     def step():
         stepper.step(timed=True)
 
+    if rank == 0:
+        stepper.stage_events(args.steps, skip=args.warmup)
     elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device)
+    in_step = stepper.stage_times_ms() if rank == 0 else []
 
     wino = wino_roofline(stepper) if rank == 0 and dtype == torch.float32 else None
     if rank == 0:
@@ -914,7 +945,10 @@ def main():
         rowmax_bytes = ((64512000 + 806400) * esz // 4 + 806400) * batch
         stage_bytes = HEAD_BYTES_PER_IMAGE * esz // 4 * batch
         achieved = rowmax_bytes / (ms_rowmax * 1e-3) / 1e9
-        stage = stage_bytes / (ms_stage * 1e-3) / 1e9
+        b2b = stage_bytes / (ms_stage * 1e-3) / 1e9
+        # the headline roofline figure: the stage's average duration INSIDE the timed steps
+        ms_in_step = sum(in_step) / len(in_step) if in_step else ms_stage
+        stage = stage_bytes / (ms_in_step * 1e-3) / 1e9
         out = {
             'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN' if headline else
                       'images/sec at 1333x800, IoU-aware RetinaNet (%s)' % args.config,
@@ -939,15 +973,26 @@ def main():
             'roofline': {'bound': 'hbm',
                          'kernel': 'decode stage: k_rowmax + k_sel_filter + k_sel_final + k_gather '
                                    '(SURVEY 8d unit)',
-                         'timing': 'HIP events on the launch stream around 10 back-to-back passes '
-                                   'of the stage after the timed region, best of 5 (inter-kernel '
-                                   'gaps included; kernel-busy time: profiles/)',
+                         'timing': ('HIP events recorded by the library on the launch stream in front '
+                                    'of the stage\'s first launch and behind its last one, in every '
+                                    'step of the timed region (ia_profile_stage_events); average '
+                                    'over the %d timed steps' % len(in_step)) if in_step else
+                                   'back-to-back passes after the timed region (see back_to_back)',
                          'achieved': round(stage, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(stage / HBM_PEAK_GBS, 4),
+                         'in_step_ms': {'mean': round(ms_in_step, 4),
+                                        'min': round(min(in_step), 4), 'max': round(max(in_step), 4),
+                                        'steps': len(in_step)} if in_step else None,
+                         'back_to_back': {'timing': 'HIP events around 10 back-to-back passes of the '
+                                                    'stage after the timed region, best of 5 '
+                                                    '(inter-kernel gaps included)',
+                                          'avg_launch_ms': round(ms_stage, 4),
+                                          'achieved': round(b2b, 1),
+                                          'frac': round(b2b / HBM_PEAK_GBS, 4)},
                          'traffic': stage_traffic() if headline else None,
                          'traffic_source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                            'separate passes, same batch-8 launches)' % PMC_PROFILE,
-                         'bytes_per_launch': stage_bytes, 'avg_launch_ms': round(ms_stage, 4),
+                         'bytes_per_launch': stage_bytes, 'avg_launch_ms': round(ms_in_step, 4),
                          'rowmax': {'kernel': rm_kernel.split('::')[1].split('<')[0],
                                     'bytes_per_launch': rowmax_bytes,
                                     'avg_launch_ms': round(ms_rowmax, 4),

@@ -169,6 +169,12 @@ int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch,
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
 size_t ia_get_bboxes_status_offset(const ia_head_geom *g, int batch);
 int ia_debug_fused_spin_limit(int64_t limit);
+/* Profiling hook (bench.py): two caller-owned hipEvent_t (as void *) that every later
+ * ia_get_bboxes / ia_get_bboxes_lazy / ia_decode_stage call records on ITS stream -- `begin` in
+ * front of the decode stage's first launch (row-max), `end` behind its last one (gather / decode) --
+ * so the stage can be timed inside real steps.  Both NULL (the default) switch it off; one NULL:
+ * IA_E_ARG.  Process-wide; the caller keeps the events alive while they are set. */
+int ia_profile_stage_events(void *begin, void *end);
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                   const float *img_hw, const float *scale_factor, int rescale, float score_thr,
                   float iou_thr, int max_per_img, void *workspace, size_t workspace_bytes,

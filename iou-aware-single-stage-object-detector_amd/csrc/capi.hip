@@ -2,6 +2,7 @@
 // whole-path driver ia_get_bboxes: five launches on the caller's stream, no
 // host synchronisation, no allocation.
 #include <string.h>
+#include <atomic>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 
@@ -290,6 +291,15 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
     return 0;
 }
 
+// ia_profile_stage_events: a pair of caller-owned HIP events recorded on the call's stream right
+// before the stage's first launch and right behind its last one (bench.py: the decode stage timed
+// INSIDE the steps of the timed region).  Both null (the default): nothing is recorded.
+static std::atomic<void *> g_stage_ev[2];
+
+static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                                 const float *img_hw, const float *scale_factor, int rescale,
+                                 char *ws, hipStream_t s, ia::WsLayout &w, ia::LevelTable &t);
+
 static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                              const float *img_hw, const float *scale_factor, int rescale,
                              void *workspace, size_t workspace_bytes, hipStream_t s,
@@ -301,6 +311,19 @@ static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int 
     if (workspace_bytes < w.total) return IA_E_WORKSPACE;
     if (((uintptr_t)workspace & 255u) != 0) return IA_E_ARG;
     char *ws = static_cast<char *>(workspace);
+    hipEvent_t e0 = (hipEvent_t)g_stage_ev[0].load(std::memory_order_acquire);
+    hipEvent_t e1 = (hipEvent_t)g_stage_ev[1].load(std::memory_order_acquire);
+    if (e0 && (rc = ia::hip_status(hipEventRecord(e0, s)))) return rc;
+    rc = decode_stage_launches(g, p, batch, dtype, img_hw, scale_factor, rescale, ws, s, w, t);
+    if (!rc && e1) rc = ia::hip_status(hipEventRecord(e1, s));
+    return rc;
+}
+
+static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
+                                 const float *img_hw, const float *scale_factor, int rescale,
+                                 char *ws, hipStream_t s, ia::WsLayout &w, ia::LevelTable &t)
+{
+    int rc;
     float *rowmax = reinterpret_cast<float *>(ws + w.off[0]);
     int32_t *cand = reinterpret_cast<int32_t *>(ws + w.off[1]);
     float *boxes = reinterpret_cast<float *>(ws + w.off[2]);
@@ -354,6 +377,14 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
                    (ia::nms_workspace_bytes(batch, w.R, t.C, noff) + 255) / 256 * 256;
     return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, fin_ws,
                                dets, labels, rows, num, s, gate);
+}
+
+int ia_profile_stage_events(void *begin, void *end)
+{
+    if ((begin == nullptr) != (end == nullptr)) return IA_E_ARG;
+    g_stage_ev[0].store(begin, std::memory_order_release);
+    g_stage_ev[1].store(end, std::memory_order_release);
+    return 0;
 }
 
 int ia_decode_stage(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,

@@ -200,6 +200,21 @@ def fused_spin_limit(limit=-1):
     _lib.check(_lib.lib().ia_debug_fused_spin_limit(int(limit)), 'ia_debug_fused_spin_limit')
 
 
+def stage_events(begin=None, end=None):
+    """ia_profile_stage_events: the decode stage of every later get_bboxes / DecodeStage call records
+    these two torch.cuda.Event(enable_timing=True) objects on its stream (in front of the row-max
+    launch, behind the gather); None, None switches the hook off.  The events must have been
+    recorded once (torch creates the HIP event lazily) and stay alive while they are set."""
+    if begin is None and end is None:
+        _lib.check(_lib.lib().ia_profile_stage_events(None, None), 'ia_profile_stage_events')
+        return
+    if not (begin.cuda_event and end.cuda_event):
+        raise ValueError('record the events once before handing them over (torch creates them lazily)')
+    _lib.check(_lib.lib().ia_profile_stage_events(C.c_void_p(begin.cuda_event),
+                                                  C.c_void_p(end.cuda_event)),
+               'ia_profile_stage_events')
+
+
 def state_workspace_for(geom, cls, reg, iou):
     """the persistent workspace `get_bboxes` uses for these head outputs (tests / telemetry)"""
     p, B, dt, g = level_ptrs(geom, list(cls), list(reg), list(iou))

@@ -161,3 +161,38 @@ def test_head_loss_stays_inside_its_workspace(ops, guarded):
         sum(v.total for v in losses.values()).backward()
     torch.cuda.synchronize()
     guarded.check()
+
+
+def test_stage_events_bracket_the_decode_stage_and_change_nothing(ops):
+    """ia_profile_stage_events (bench.py's in-step roofline timing): the two events are recorded by
+    every later get_bboxes call on its stream, the bracketed time is the decode stage's (tens of
+    microseconds at this size, far below the whole call), the detections are unchanged, and
+    (None, None) switches the hook off again."""
+    ph, pw, B = 800, 1344, 2
+    geom, _ = G.geometry(ph, pw, 1000)
+    _, dev = _heads(37, B, ph, pw, 'A', 1)
+    shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
+    plain = [t.cpu().numpy() for t in ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with pytest.raises(ValueError):
+        ops.stage_events(e0, e1)                      # not created yet
+    e0.record()
+    e1.record()
+    torch.cuda.synchronize()
+    ops.stage_events(e0, e1)
+    try:
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
+        timed = [t.cpu().numpy() for t in ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)]
+        w1.record()
+        torch.cuda.synchronize()
+        stage_ms, call_ms = e0.elapsed_time(e1), w0.elapsed_time(w1)
+    finally:
+        ops.stage_events(None, None)
+    assert 0.0 < stage_ms < call_ms, (stage_ms, call_ms)
+    for a, b in zip(plain, timed):
+        assert np.array_equal(a, b)
+    # switched off: a later call leaves the pair untouched
+    ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) == stage_ms
