@@ -120,6 +120,7 @@ class Stepper(object):
     decode stage's first launch and behind its last one (ia_profile_stage_events): the stage timed
     INSIDE the steps of the timed region (two event records per step, no synchronisation); the
     back-to-back figures of decode_stage_roofline() stay beside it."""
+    events, ev_next = (), 0                  # (class defaults: subclasses with their own __init__)
 
     def __init__(self, model, imgs, world):
         self.model, self.imgs, self.world = model, imgs, world
