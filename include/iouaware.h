@@ -117,7 +117,9 @@ int ia_select_topk_grouped(const ia_head_geom *g, const float *rowmax, int batch
  * (delta2bbox) + anchor_generator.py:53-70 (anchors regenerated, never read).
  * img_hw: (B,2) fp32 (img_shape h,w); scale_factor: (B,4) fp32.
  * boxes: (B,R,4) fp32; scores_t: (B,C,Rs) fp32 class-major fused scores;
- * best_score: (B,R) fp32 max over classes per candidate (optional, may be NULL).*/
+ * best_score: (B,R) fp32 max over classes per candidate (optional, may be NULL).
+ * Like the row-max and top-k entries: any R (IA_MAX_CANDIDATES is the capacity of the batched NMS
+ * behind ia_get_bboxes / ia_multiclass_nms, not of this stage).                      */
 int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                      const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
                      int rescale, float *boxes, float *scores_t, float *best_score, void *stream);

@@ -142,16 +142,17 @@ int ia_gather_decode(const ia_head_geom *g, const ia_level_ptrs *p, int batch, i
                      const int32_t *cand_idx, const float *img_hw, const float *scale_factor,
                      int rescale, float *boxes, float *scores_t, float *best_score, void *stream)
 {
-    ia::WsLayout w;
-    int rc = ia::ws_layout(g, batch, w);
-    if (rc) return rc;
-    if (!p) return IA_E_ARG;
+    // pure geometry like the row-max and top-k entries: any number of candidates per image (the
+    // IA_MAX_CANDIDATES capacity belongs to the batched NMS behind ia_get_bboxes, not to this stage)
     ia::LevelTable t;
-    ia::make_level_table(g, t);
+    int rc = ia::make_level_table(g, t);
+    if (rc) return rc;
+    if (!p || batch < 1) return IA_E_ARG;
+    const int Rs = (t.cand_off[t.num_levels] + 63) / 64 * 64;
     ia::BaseAnchors ba;
     ia::base_from_geom(g, ba);
     return ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand_idx, img_hw,
-                             scale_factor, rescale, boxes, scores_t, best_score, w.Rs,
+                             scale_factor, rescale, boxes, scores_t, best_score, Rs,
                              (hipStream_t)stream);
 }
 

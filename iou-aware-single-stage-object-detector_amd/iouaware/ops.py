@@ -276,6 +276,11 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     dev = cls[0].device
     L = _lib.lib()
     nbytes = L.ia_get_bboxes_workspace_bytes(geom.ref(), B)
+    if (nbytes == 0 and geom.R > _lib.IA_MAX_CANDIDATES) or max_per_img > _lib.IA_MAX_PER_IMG:
+        # beyond the batched entry's capacities -- the reference has none (bbox_nms.py:33-56 takes
+        # any number of candidates and any max_num): the stage entries, then one NMS per class
+        return _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr,
+                                     iou_thr, max_per_img, debug)
     if nbytes == 0:
         raise _lib.IouAwareLibraryError('unsupported geometry / batch for ia_get_bboxes')
     ws = _state_workspace(dev, nbytes, (geom.key, geom.layout, B, dt))
@@ -310,6 +315,55 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
                keep_rows=view(5, torch.int32, (B, geom.C, geom.Rs)),
                fused_fallbacks=torch.tensor(get_bboxes_status(geom, B, ws)[1]))
     return dets, labels, rows, num, dbg
+
+
+def _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr, iou_thr,
+                          max_per_img, debug=False):
+    """get_bboxes beyond the capacities of the batched C-ABI entry (more than IA_MAX_CANDIDATES
+    candidates per image -- e.g. nms_pre = 2000 on five large levels -- or max_per_img above
+    IA_MAX_PER_IMG): the decode stage through its stage entries (row-max, exact top-k, gather /
+    decode: pure geometry, any size), then multiclass_nms AS THE REFERENCE WRITES IT
+    (mmdet/core/post_processing/bbox_nms.py:33-56): one NMS per class on the single-problem entry
+    (ia_nms takes any n), class-major concatenation, and the score sort only when more than
+    max_per_img survive (stable: equal scores keep their concatenation order, this build's canonical
+    order).  Same return values as get_bboxes; a host synchronisation per class problem -- the slow,
+    unbounded route."""
+    geom = geometry_for(geom, cls, reg, iou)
+    rowmax = decode_fuse_rowmax(geom, cls, reg, iou)
+    cand = select_topk(geom, rowmax)
+    boxes, scores_t, _ = gather_decode(geom, cls, reg, iou, cand, img_shapes, scale_factors, rescale)
+    B, R, Cn, dev = boxes.shape[0], geom.R, geom.C, boxes.device
+    dets = torch.zeros((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.full((B, max_per_img), -1, dtype=torch.int32, device=dev)
+    rows = torch.full((B, max_per_img), -1, dtype=torch.int32, device=dev)
+    num = torch.zeros((B,), dtype=torch.int32, device=dev)
+    kc = torch.zeros((B, Cn), dtype=torch.int32, device=dev)
+    kr = torch.zeros((B, Cn, geom.Rs), dtype=torch.int32, device=dev) if debug else None
+    for b in range(B):
+        over = scores_t[b, :, :R] > score_thr                       # (C, R)
+        live = over.any(dim=1).nonzero().flatten().tolist()         # classes with a survivor of the threshold
+        d_all, l_all, r_all = [], [], []
+        for c in live:
+            inds = over[c].nonzero().flatten()                      # ascending candidate rows
+            d = torch.cat([boxes[b, inds], scores_t[b, c, inds, None]], dim=1)
+            keep = nms_indices(d, iou_thr)                          # ascending, like nms_cpu.cpp:58
+            d_all.append(d[keep]); r_all.append(inds[keep])
+            l_all.append(torch.full((keep.numel(),), c, dtype=torch.int32, device=dev))
+            kc[b, c] = keep.numel()
+            if debug:
+                kr[b, c, :keep.numel()] = inds[keep].to(torch.int32)
+        if not d_all:
+            continue
+        d_all, l_all, r_all = torch.cat(d_all), torch.cat(l_all), torch.cat(r_all)
+        if d_all.shape[0] > max_per_img:
+            order = torch.sort(d_all[:, 4], descending=True, stable=True)[1][:max_per_img]
+            d_all, l_all, r_all = d_all[order], l_all[order], r_all[order]
+        n = d_all.shape[0]
+        dets[b, :n], labels[b, :n], rows[b, :n], num[b] = d_all, l_all, r_all.to(torch.int32), n
+    if not debug:
+        return dets, labels, rows, num
+    return dets, labels, rows, num, dict(rowmax=rowmax, cand_idx=cand, boxes=boxes, scores_t=scores_t,
+                                         keep_count=kc, keep_rows=kr, fused_fallbacks=torch.tensor(0))
 
 
 class DecodeStage(object):

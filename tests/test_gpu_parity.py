@@ -535,3 +535,23 @@ def test_multiclass_nms_wrapper_max_num_minus_one_quirk(ops, golden_dir):
     # sorted by score, and the dropped one is the global minimum of the survivors
     assert (np.diff(f['bboxes_m1'][:, 4]) <= 0).all()
     assert f['bboxes_all'][:, 4].min() < f['bboxes_m1'][:, 4].min()
+
+
+@pytest.mark.parametrize('ph,pw,B,nms_pre,max_per_img,kind', [
+    (800, 928, 1, 2000, 100, 'C'),        # 2000 + 2000 + 2000 + 1755 + 504 = 8259 candidates per image > IA_MAX_CANDIDATES
+    (416, 1248, 2, 4096, 300, 'A'),       # nms_pre at IA_MAX_NMS_PRE
+    (256, 320, 2, 1000, 1500, 'B'),       # max_per_img > IA_MAX_PER_IMG
+])
+def test_get_bboxes_beyond_the_batched_capacity(ops, oracle_lib, ph, pw, B, nms_pre, max_per_img, kind):
+    """The reference's get_bboxes / multiclass_nms take any nms_pre and any max_per_img
+    (iou_aware_retina_head.py:499-564, bbox_nms.py:33-56); the batched C-ABI entry holds
+    IA_MAX_CANDIDATES candidates and IA_MAX_PER_IMG detections per image.  Beyond that
+    ops.get_bboxes takes the stage entries + one NMS per class (ops._get_bboxes_per_class) and must
+    give the oracle's result, every stage bit for bit, in both layouts."""
+    from iouaware import _lib
+    geom, base = G.geometry(ph, pw, nms_pre)
+    assert geom.R > _lib.IA_MAX_CANDIDATES or max_per_img > _lib.IA_MAX_PER_IMG
+    cls, reg, iou = synth.head_outputs(77, B, ph, pw, kind)
+    metas = [synth.img_meta(ph - 3, pw - 5, ph, pw, 1.0) for _ in range(B)]
+    res = check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, max_per_img)
+    assert all(len(r['det_labels']) > 0 for r in res)
