@@ -244,3 +244,19 @@ def test_lazy_two_tier_clustered_scenes(per_cluster):
     assert int(full[3].min()) == 100
     for name, a, b in zip(('dets', 'labels', 'rows', 'num'), full, lz):
         assert torch.equal(a, b), (per_cluster, name)
+
+
+@pytest.mark.parametrize('seed', [1012, 1017, 1018, 1065, 1067] + list(range(7000, 7015)))
+def test_get_bboxes_random_configurations(seed):
+    """tools/fuzz_get_bboxes.py's generator (random pyramid sizes, batches, nms_pre incl. beyond the
+    batched entry's capacity, thresholds, score statistics, fp32 / bf16; both layouts, complete and
+    lazy NMS) against the oracle, every stage bit for bit.  The first five seeds are the
+    configurations that found the capacity gap of round 4 (ops._get_bboxes_per_class)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_get_bboxes', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools',
+                                        'fuzz_get_bboxes.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run_case(seed)

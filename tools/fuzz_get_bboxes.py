@@ -19,12 +19,12 @@ from iouaware import ops  # noqa: E402
 import test_gpu_parity as P  # noqa: E402
 
 oracle.build()
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t0 = time.time()
-bad = 0
-for i in range(cases):
-    rs = np.random.RandomState(seed0 + i)
+
+
+def run_case(seed):
+    """one random configuration (drawn from `seed`) through check_against_oracle; raises on the
+    first mismatch; -> the configuration as text"""
+    rs = np.random.RandomState(seed)
     big = rs.rand() < 0.15
     ph = 32 * int(rs.randint(2, 26 if big else 12))
     pw = 32 * int(rs.randint(2, 43 if big else 16))
@@ -38,19 +38,31 @@ for i in range(cases):
     dtype = torch.bfloat16 if rs.rand() < 0.2 else torch.float32
     ih, iw = ph - int(rs.randint(0, 32)), pw - int(rs.randint(0, 32))
     sf = float(rs.choice([1.0, 1.0, 0.75, 1.6666666]))
-    cls, reg, iou = synth.head_outputs(seed0 + i, B, ph, pw, kind)
+    cls, reg, iou = synth.head_outputs(seed, B, ph, pw, kind)
     if dtype == torch.bfloat16:
         cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
     geom, base = G.geometry(ph, pw, nms_pre)
     metas = [synth.img_meta(ih, iw, ph, pw, sf) for _ in range(B)]
-    tag = 'case %d seed %d: %dx%d B=%d nms_pre=%d kind=%s thr=%.2f iou=%.1f max=%d rescale=%d %s' % (
-        i, seed0 + i, ph, pw, B, nms_pre, kind, score_thr, iou_thr, max_per_img, rescale, str(dtype)[6:])
+    tag = 'seed %d: %dx%d B=%d nms_pre=%d kind=%s thr=%.2f iou=%.1f max=%d rescale=%d %s' % (
+        seed, ph, pw, B, nms_pre, kind, score_thr, iou_thr, max_per_img, rescale, str(dtype)[6:])
     try:
         P.check_against_oracle(ops, oracle, cls, reg, iou, geom, base, metas, rescale, score_thr, iou_thr,
                                max_per_img, dtype=dtype)
-        print('ok   ' + tag, flush=True)
-    except Exception as exc:                            # keep hunting
-        bad += 1
-        print('FAIL ' + tag + ' -> %s: %s' % (type(exc).__name__, str(exc)[:300]), flush=True)
-print('%d cases, %d failures, %.0f s' % (cases, bad, time.time() - t0))
-sys.exit(1 if bad else 0)
+    except Exception as exc:
+        raise AssertionError(tag + ' -> %s: %s' % (type(exc).__name__, str(exc)[:300])) from exc
+    return tag
+
+
+if __name__ == '__main__':
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    bad = 0
+    for i in range(cases):
+        try:
+            print('ok   ' + run_case(seed0 + i), flush=True)
+        except AssertionError as exc:                   # keep hunting
+            bad += 1
+            print('FAIL ' + str(exc), flush=True)
+    print('%d cases, %d failures, %.0f s' % (cases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
