@@ -685,7 +685,10 @@ def conv3x3_bf16_levels(xs, wp, bias, cout, ys, relu=False, cin=None):
         # channels-last (possibly a channel slice): stride of W = channels of the underlying tensor
         if t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(1) != 1:
             raise TypeError('conv3x3_bf16_levels needs channels-last bf16 tensors')
-        st = t.stride(3) if t.shape[3] > 1 else (t.stride(2) if t.shape[2] > 1 else t.shape[1])
+        # (a 1 x 1 map of a batch: the pixel stride is the image stride -- P6 / P7 of a small input,
+        # where the cls / reg halves are channel slices of a 2F-wide activation)
+        st = t.stride(3) if t.shape[3] > 1 else (t.stride(2) if t.shape[2] > 1 else
+                                                 (t.stride(0) if t.shape[0] > 1 else t.shape[1]))
         if (t.shape[2] > 1 and t.shape[3] > 1 and t.stride(2) != t.shape[3] * st) or \
                 (t.shape[0] > 1 and t.stride(0) != t.shape[2] * t.shape[3] * st):
             raise TypeError('conv3x3_bf16_levels: tensor is not a dense channels-last (slice)')

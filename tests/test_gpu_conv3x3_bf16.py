@@ -51,8 +51,10 @@ def test_conv3x3_bf16_levels_groups_slices_and_odd_widths():
     the last one partial) -- against fp64 convolutions of the bf16-rounded inputs"""
     from iouaware import ops
     g = torch.Generator(device='cuda').manual_seed(11)
-    sizes = [(28, 40), (14, 20), (7, 10), (4, 5), (2, 3)]
-    B, F = 2, 256
+    # (the 1 x 1 and 1 x 2 maps: P6 / P7 of a 64 x 64 input -- a channel slice of a 1 x 1 map has the image
+    # stride as its pixel stride; found by tools/fuzz_fused_model.py)
+    sizes = [(28, 40), (14, 20), (7, 10), (1, 2), (1, 1)]
+    B, F = 3, 256
     cl = torch.channels_last
     acts = [torch.randn(B, 2 * F, h, w, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=cl)
             for h, w in sizes]
