@@ -260,3 +260,39 @@ def test_get_bboxes_random_configurations(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run_case(seed)
+
+
+def _edge_inputs(name):
+    rs = np.random.RandomState(3)
+    if name.startswith('batch'):
+        B, ph, pw = {'batch33': (33, 128, 160), 'batch64': (64, 64, 96), 'batch17': (17, 256, 320)}[name]
+        return synth.head_outputs(B, B, ph, pw, 'A') + (ph, pw, 1000, 100)
+    if name.startswith('sd'):
+        sd = float(name[2:])
+        ph, pw = 192, 256
+        c, r, i = synth.head_outputs(5, 2, ph, pw, 'A')
+        c = [(rs.standard_normal(x.shape) * sd).astype(np.float32) for x in c]
+        i = [(rs.standard_normal(x.shape) * sd).astype(np.float32) for x in i]
+        r = [(rs.standard_normal(x.shape) * min(sd, 20.0)).astype(np.float32) for x in r]
+        return c, r, i, ph, pw, 1000, 100
+    if name.startswith('equal'):
+        ph, pw = 160, 224
+        c, r, i = synth.head_outputs(6, 2, ph, pw, 'A')
+        return [np.full_like(x, float(name[5:])) for x in c], r, [np.zeros_like(x) for x in i], ph, pw, 300, 50
+    ph, pw = 128, 128                                     # 'delta50': every box delta at the exp clamp
+    c, r, i = synth.head_outputs(8, 2, ph, pw, 'B')
+    return c, [np.where(rs.rand(*x.shape) < 0.5, 50.0, -50.0).astype(np.float32) for x in r], i, ph, pw, 1000, 100
+
+
+@pytest.mark.parametrize('name', ['batch33', 'batch64', 'batch17', 'sd30', 'sd100', 'sd10000', 'equal0', 'equal-3',
+                                  'delta50'])
+def test_get_bboxes_edge_inputs(oracle_lib, name):
+    """batches beyond the by-pointer entries' 16, saturating logits (sigmoid at 0 / 1, scores tied in
+    blocks), all-equal scores (every anchor on the top-k cut), box deltas far beyond the exp clamp:
+    every stage bit for bit against the oracle, both layouts, complete and lazy NMS"""
+    from iouaware import ops
+    import test_gpu_parity as P
+    cls, reg, iou, ph, pw, nms_pre, mp = _edge_inputs(name)
+    geom, base = G.geometry(ph, pw, nms_pre)
+    metas = [synth.img_meta(ph - 3, pw - 5, ph, pw, 1.0) for _ in range(cls[0].shape[0])]
+    P.check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, mp)
