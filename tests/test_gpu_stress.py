@@ -296,3 +296,55 @@ def test_get_bboxes_edge_inputs(oracle_lib, name):
     geom, base = G.geometry(ph, pw, nms_pre)
     metas = [synth.img_meta(ph - 3, pw - 5, ph, pw, 1.0) for _ in range(cls[0].shape[0])]
     P.check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, mp)
+
+
+def test_serving_threads_with_their_own_streams():
+    """four host threads, each with its own stream and its own input size, running the fused
+    image -> detections path concurrently (per-stream scratch / workspaces / GEMM handles, the
+    library's caches behind mutexes): every iteration equals the thread's single-threaded result
+    (labels exact, boxes and scores within 1e-3)"""
+    import threading
+    import iouaware
+    from iouaware.config import ConfigDict
+    from iouaware.fuse import fuse_inference
+    from test_host_model import R50_MODEL, TEST_CFG
+    torch.manual_seed(1)
+    m = iouaware.build_detector(ConfigDict(R50_MODEL), test_cfg=ConfigDict(TEST_CFG)).eval()
+    with torch.no_grad():
+        synth.e2e_fill_state(m.state_dict(), 9)
+    m = m.cuda()
+    fuse_inference(m, winograd=True)
+    m = m.to(memory_format=torch.channels_last)
+    T = 4
+    xs = [torch.randn(2, 3, 192 + 32 * t, 256, device='cuda').contiguous(memory_format=torch.channels_last)
+          for t in range(T)]
+    metas = [[synth.img_meta(190 + 32 * t, 250, 192 + 32 * t, 256) for _ in range(2)] for t in range(T)]
+    with torch.no_grad():
+        ref = [[v.clone() for v in m.simple_test_device(xs[t], metas[t], rescale=True)] for t in range(T)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for it in range(6):
+                    o = m.simple_test_device(xs[t], metas[t], rescale=True)
+                    s.synchronize()
+                    if not torch.equal(o[3], ref[t][3]):
+                        errs.append((t, it, 'num'))
+                        continue
+                    for b in range(2):
+                        n = int(o[3][b])
+                        if not torch.equal(o[1][b, :n], ref[t][1][b, :n]):
+                            errs.append((t, it, b, 'labels'))
+                        elif float((o[0][b, :n] - ref[t][0][b, :n]).abs().max()) > 1e-3:
+                            errs.append((t, it, b, 'boxes'))
+        except Exception as exc:                           # a worker's exception must fail the test
+            errs.append((t, repr(exc)[:300]))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs[:5]
