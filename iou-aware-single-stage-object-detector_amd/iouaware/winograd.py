@@ -15,6 +15,7 @@ Numerics: fp32 throughout; the Winograd transforms reassociate the sums, outputs
 direct convolution to ~1e-5 of the activation scale (tests/test_gpu_winograd.py).  The weights are
 transformed once (fp64 -> fp32) when the runner is built: build it AFTER loading a checkpoint.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -71,6 +72,24 @@ def _scratch(device, name, shape):
     if b is None or b.numel() < n:
         b = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
     return b[:n].view(*shape)
+
+
+_PLAN_ENTRIES = 4     # plans kept per layer object: the head's plan owns two ping-pong activation sets
+                      # (2 x B x 2F x sum(HW) floats: 92 MB at batch 1, 736 MB at batch 8 of 800 x 1344)
+
+
+def _plan_for(plans, key, make):
+    """least-recently-used cache of _Plan objects: evaluation meets many pad shapes (keep-ratio
+    resize, padded to /32), and a plan per shape kept for the life of the model pinned its
+    activation buffers for good (the growth ADVICE r3 found in the bf16 head's buffers)"""
+    plan = plans.get(key)
+    if plan is None:
+        while len(plans) >= _PLAN_ENTRIES:
+            plans.popitem(last=False)
+        plan = plans[key] = make()
+    else:
+        plans.move_to_end(key)
+    return plan
 
 
 class _Plan(object):
@@ -181,7 +200,7 @@ class WinogradConv3x3(object):
         self.cin, self.cout = self.u.shape[1], self.u.shape[2]
         if self.cout % 4:
             raise ValueError('output channels must be a multiple of 4')
-        self._plans = {}
+        self._plans = collections.OrderedDict()
 
     def usable(self, x):
         # raw kernels, no autograd graph: grad mode off, or an input that carries no gradient
@@ -195,9 +214,7 @@ class WinogradConv3x3(object):
         # the plan owns scratch buffers (V, M): one per stream, so forwards on different streams
         # do not share them
         key = (x.shape[0], tuple(x.shape[-2:]), x.device, torch.cuda.current_stream().cuda_stream)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = _Plan([tuple(x.shape[-2:])], x.shape[0], x.device)
+        plan = _plan_for(self._plans, key, lambda: _Plan([tuple(x.shape[-2:])], x.shape[0], x.device))
         v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)), pre)
         m = batched_gemm(v, self.u, plan.buf('m', (36, plan.T, self.cout)))
         y = torch.empty((x.shape[0], self.cout) + tuple(x.shape[-2:]), dtype=torch.float32,
@@ -252,7 +269,7 @@ class WinogradHead(object):
         b_ri[:self.c_reg] = head.retina_reg.bias.detach().float()
         b_ri[self.c_reg:n_ri] = head.retina_iou.bias.detach().float()
         self.b_ri = b_ri.contiguous()
-        self._plans = {}
+        self._plans = collections.OrderedDict()
 
     def usable(self, feats):
         return all(_usable(x) and x.shape[1] == self.cin for x in feats) \
@@ -263,9 +280,7 @@ class WinogradHead(object):
         B = feats[0].shape[0]
         sizes = [tuple(x.shape[-2:]) for x in feats]
         key = (B, tuple(sizes), feats[0].device, torch.cuda.current_stream().cuda_stream)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = _Plan(sizes, B, feats[0].device)
+        plan = _plan_for(self._plans, key, lambda: _Plan(sizes, B, feats[0].device))
         T, F = plan.T, self.F
         # layer 0
         v = input_transform(plan, feats, 1, plan.buf('v', (36, T, self.cin)))

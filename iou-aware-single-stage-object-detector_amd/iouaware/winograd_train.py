@@ -25,6 +25,7 @@ multiplications per 4x4 output tile instead of MIOpen's 64, and all levels in on
 Activations are channels-last fp32; the transformed weights are recomputed from the parameters
 in every call (they change every iteration).
 """
+import collections
 import ctypes
 
 import torch
@@ -35,14 +36,11 @@ from . import winograd as W
 def _plan(xs):
     key = (xs[0].shape[0], tuple(tuple(x.shape[-2:]) for x in xs), xs[0].device,
            torch.cuda.current_stream().cuda_stream)
-    plan = _PLANS.get(key)
-    if plan is None:
-        plan = _PLANS[key] = W._Plan([tuple(x.shape[-2:]) for x in xs], xs[0].shape[0],
-                                     xs[0].device)
-    return plan
+    return W._plan_for(_PLANS, key, lambda: W._Plan([tuple(x.shape[-2:]) for x in xs], xs[0].shape[0],
+                                                    xs[0].device))
 
 
-_PLANS = {}
+_PLANS = collections.OrderedDict()       # least recently used first, W._PLAN_ENTRIES kept (multi-scale training)
 
 
 def _cl(t):

@@ -135,3 +135,23 @@ def test_batched_gemm_stream_matches_fp64_and_library(k, n, batch, rows):
     finally:
         wg.STREAM_BMM = True
     assert float((out - lib).abs().max()) < 1e-5 * float(lib.abs().max())
+
+
+def test_winograd_plans_are_a_bounded_lru():
+    """evaluation meets many pad shapes: the per-layer plan caches (the head's plan owns two
+    activation sets) keep the most recently used few and give the same result when a shape
+    comes back after its plan was evicted"""
+    from iouaware import winograd as W
+    g = torch.Generator(device='cuda').manual_seed(3)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    layer = W.WinogradConv3x3(conv.weight, conv.bias, relu=True)
+    xs = [torch.randn(1, 64, 8 + 4 * i, 12, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+          for i in range(W._PLAN_ENTRIES + 3)]
+    with torch.no_grad():
+        first = layer(xs[0]).clone()
+        for x in xs[1:]:
+            layer(x)
+        assert len(layer._plans) == W._PLAN_ENTRIES
+        again = layer(xs[0])
+    assert torch.equal(first, again)
+    assert len(layer._plans) == W._PLAN_ENTRIES
