@@ -264,6 +264,9 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
     cls, reg, iou = list(cls), list(reg), list(iou)
     if soft is not None:
         geom = geometry_for(geom, cls, reg, iou)
+        if geom.R > _lib.IA_MAX_CANDIDATES or max_per_img > _lib.IA_MAX_PER_IMG:
+            return _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr,
+                                         iou_thr, max_per_img, debug, soft=soft)
         cand = select_topk(geom, decode_fuse_rowmax(geom, cls, reg, iou))
         boxes, scores_t, _ = gather_decode(geom, cls, reg, iou, cand, img_shapes, scale_factors,
                                            rescale)
@@ -318,7 +321,7 @@ def get_bboxes(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_th
 
 
 def _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescale, score_thr, iou_thr,
-                          max_per_img, debug=False):
+                          max_per_img, debug=False, soft=None):
     """get_bboxes beyond the capacities of the batched C-ABI entry (more than IA_MAX_CANDIDATES
     candidates per image -- e.g. nms_pre = 2000 on five large levels -- or max_per_img above
     IA_MAX_PER_IMG): the decode stage through its stage entries (row-max, exact top-k, gather /
@@ -326,8 +329,10 @@ def _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescal
     (mmdet/core/post_processing/bbox_nms.py:33-56): one NMS per class on the single-problem entry
     (ia_nms takes any n), class-major concatenation, and the score sort only when more than
     max_per_img survive (stable: equal scores keep their concatenation order, this build's canonical
-    order).  Same return values as get_bboxes; a host synchronisation per class problem -- the slow,
-    unbounded route."""
+    order).  soft = dict(method=, sigma=, min_score=): soft-NMS per class instead (detections carry the
+    decayed scores, a class's survivors in selection order; up to IA_MAX_CANDIDATES boxes per class
+    problem).  Same return values as get_bboxes; a host synchronisation per class problem -- the
+    slow, unbounded route."""
     geom = geometry_for(geom, cls, reg, iou)
     rowmax = decode_fuse_rowmax(geom, cls, reg, iou)
     cand = select_topk(geom, rowmax)
@@ -346,8 +351,12 @@ def _get_bboxes_per_class(geom, cls, reg, iou, img_shapes, scale_factors, rescal
         for c in live:
             inds = over[c].nonzero().flatten()                      # ascending candidate rows
             d = torch.cat([boxes[b, inds], scores_t[b, c, inds, None]], dim=1)
-            keep = nms_indices(d, iou_thr)                          # ascending, like nms_cpu.cpp:58
-            d_all.append(d[keep]); r_all.append(inds[keep])
+            if soft is not None:
+                kept, keep = soft_nms_dets(d, iou_thr, **soft)      # selection order, decayed scores
+            else:
+                keep = nms_indices(d, iou_thr)                      # ascending, like nms_cpu.cpp:58
+                kept = d[keep]
+            d_all.append(kept); r_all.append(inds[keep])
             l_all.append(torch.full((keep.numel(),), c, dtype=torch.int32, device=dev))
             kc[b, c] = keep.numel()
             if debug:

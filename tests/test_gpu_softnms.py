@@ -158,3 +158,29 @@ def test_multiclass_nms_wrapper_soft(oracle_lib):
     r = oracle_lib.multiclass_soft_nms(boxes, scores[:, 1:], 0.05, 0.3, 'linear', 0.5, 0.05, 50)
     assert np.array_equal(l.cpu().numpy(), r['det_labels'])
     assert G.same_bits(d.cpu().numpy(), r['det_bboxes'])
+
+
+def test_get_bboxes_soft_beyond_the_batched_capacity(ops, oracle_lib):
+    """test_cfg.nms.type = 'soft_nms' with more candidates per image than the batched entry holds
+    (nms_pre = 2000 on a 800 x 928 pyramid: 8 259): the stage entries + one soft-NMS per class
+    (ops._get_bboxes_per_class) against the oracle, like test_get_bboxes_soft_vs_oracle"""
+    from iouaware import _lib
+    ph, pw, B, nms_pre = 800, 928, 1, 2000
+    cls, reg, iou = synth.head_outputs(78, B, ph, pw, 'C')
+    geom, base = G.geometry(ph, pw, nms_pre)
+    assert geom.R > _lib.IA_MAX_CANDIDATES
+    kw = dict(iou_thr=0.5, method='linear', sigma=0.5, min_score=0.05)
+    soft = {k: v for k, v in kw.items() if k != 'iou_thr'}
+    dets, labels, rows, num, dbg = ops.get_bboxes(geom, G.to_dev(cls), G.to_dev(reg), G.to_dev(iou), [(797, 925, 3)],
+                                                  [1.0], True, 0.05, kw['iou_thr'], 100, debug=True, soft=soft)
+    pre, r = _soft_oracle(oracle_lib, cls, reg, iou, 0, base, (797, 925), 1.0, nms_pre, 0.05, kw, 100)
+    k = int(num[0])
+    assert k == r['det_bboxes'].shape[0] and k > 0
+    kc = dbg['keep_count'][0].cpu().numpy()
+    assert np.array_equal(kc, r['keep_count'])
+    kr = dbg['keep_rows'][0].cpu().numpy()
+    for c in range(synth.C):
+        assert np.array_equal(kr[c, :kc[c]], r['keep_rows'][c, :kc[c]]), c
+    assert np.array_equal(labels[0, :k].cpu().numpy(), r['det_labels'])
+    assert np.array_equal(rows[0, :k].cpu().numpy(), r['det_rows'])
+    assert G.same_bits(dets[0, :k].cpu().numpy(), r['det_bboxes'])
