@@ -45,6 +45,9 @@ extern "C" {
 #define IA_LAYOUT_NCHW 0
 #define IA_LAYOUT_NHWC 1     /* needs C * sizeof(dtype) to be a multiple of 16, <= 512 bytes */
 
+#define IA_CLS_SIGMOID 0
+#define IA_CLS_SOFTMAX 1
+
 #define IA_LOSS_SLOTS 64     /* partial sums written by the *_fwd loss kernels */
 
 #define IA_E_ARG (-1)        /* invalid argument / unsupported size */
@@ -59,7 +62,7 @@ extern "C" {
 typedef struct ia_head_geom {
     int32_t num_levels;                 /* L <= IA_MAX_LEVELS */
     int32_t num_anchors;                /* A <= IA_MAX_ANCHORS */
-    int32_t num_classes;                /* C, sigmoid classes (80) */
+    int32_t num_classes;                /* C, foreground classes (80): columns of scores_t / labels */
     int32_t nms_pre;                    /* <= 0: no per-level top-k */
     int32_t H[IA_MAX_LEVELS];
     int32_t W[IA_MAX_LEVELS];
@@ -67,6 +70,14 @@ typedef struct ia_head_geom {
     float base_anchors[IA_MAX_LEVELS][IA_MAX_ANCHORS][4];  /* AnchorGenerator.base_anchors */
     float means[4], stds[4];            /* target_means / target_stds */
     int32_t layout;                     /* IA_LAYOUT_*: memory order of the head outputs */
+    /* classification activation (iou_aware_retina_head.py:504-507,538-541).
+     * IA_CLS_SIGMOID: cls has A*C channels, score_c = sqrt(sigmoid(x_c)) * sqrt(sigmoid(iou)).
+     * IA_CLS_SOFTMAX (use_sigmoid_cls=False): cls has A*(C+1) channels, channel 0 of an anchor is
+     * the background; score_c = sqrt(softmax(x)_{c+1}) * sqrt(sigmoid(iou)) for c = 0..C-1 and the
+     * row maximum runs over the foreground columns only (scores[:, 1:].max).  Everything behind the
+     * gather (NMS, labels) is the same.  Covers the inference entries (row-max, top-k, gather,
+     * ia_get_bboxes*, ia_decode_stage); the loss entries are sigmoid-only.                       */
+    int32_t cls_activation;
 } ia_head_geom;
 
 /* Per-level device pointers of the three head outputs, each (B, ch, H, W). */
@@ -175,7 +186,10 @@ int ia_debug_fused_spin_limit(int64_t limit);
  * ia_get_bboxes / ia_get_bboxes_lazy / ia_decode_stage call records on ITS stream -- `begin` in
  * front of the decode stage's first launch (row-max), `end` behind its last one (gather / decode) --
  * so the stage can be timed inside real steps.  Both NULL (the default) switch it off; one NULL:
- * IA_E_ARG.  Process-wide; the caller keeps the events alive while they are set. */
+ * IA_E_ARG.  The pair belongs to ONE stream: the first stage call after installation binds the
+ * hook to its stream and calls on other streams do not record (no cross-stream event records from
+ * concurrent callers).  The caller keeps the events alive while they are set and clears the hook
+ * (NULL, NULL) before releasing them. */
 int ia_profile_stage_events(void *begin, void *end);
 int ia_get_bboxes(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                   const float *img_hw, const float *scale_factor, int rescale, float score_thr,

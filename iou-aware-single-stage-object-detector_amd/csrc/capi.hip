@@ -122,7 +122,10 @@ int ia_decode_fuse_rowmax_grouped(const ia_head_geom *g, const ia_level_ptrs *p,
     if (!p || batch < 1 || !select_workspace) return IA_E_ARG;
     if (workspace_bytes < ia::select_workspace_bytes(t, batch)) return IA_E_WORKSPACE;
     float *groupmax = ia::select_workspace_groupmax(t, batch, select_workspace);
-    return ia::launch_rowmax(t, *p, batch, dtype, rowmax, (hipStream_t)stream, groupmax);
+    rc = ia::launch_rowmax(t, *p, batch, dtype, rowmax, (hipStream_t)stream, groupmax);
+    if (!rc && t.softmax)       // the softmax row-score kernel does not emit the group maxima
+        rc = ia::launch_groupmax(t, rowmax, batch, select_workspace, (hipStream_t)stream);
+    return rc;
 }
 
 int ia_select_topk_grouped(const ia_head_geom *g, const float *rowmax, int batch,
@@ -295,7 +298,13 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
 // ia_profile_stage_events: a pair of caller-owned HIP events recorded on the call's stream right
 // before the stage's first launch and right behind its last one (bench.py: the decode stage timed
 // INSIDE the steps of the timed region).  Both null (the default): nothing is recorded.
+// The hook is scoped to ONE stream (the stream current when it was installed is not known to the
+// library, so the first stage call after installation binds it; ia_profile_stage_events(NULL,
+// NULL) unbinds): calls on other streams / from other models in the process do not record into the
+// same events.  The caller clears the hook before releasing the events.
 static std::atomic<void *> g_stage_ev[2];
+static std::atomic<void *> g_stage_stream{nullptr};
+static std::atomic<int> g_stage_bound{0};
 
 static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                                  const float *img_hw, const float *scale_factor, int rescale,
@@ -314,6 +323,11 @@ static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int 
     char *ws = static_cast<char *>(workspace);
     hipEvent_t e0 = (hipEvent_t)g_stage_ev[0].load(std::memory_order_acquire);
     hipEvent_t e1 = (hipEvent_t)g_stage_ev[1].load(std::memory_order_acquire);
+    if (e0) {
+        int unbound = 0;
+        if (g_stage_bound.compare_exchange_strong(unbound, 1)) g_stage_stream.store((void *)s, std::memory_order_release);
+        else if (g_stage_stream.load(std::memory_order_acquire) != (void *)s) e0 = e1 = nullptr;   // another stream's call
+    }
     if (e0 && (rc = ia::hip_status(hipEventRecord(e0, s)))) return rc;
     rc = decode_stage_launches(g, p, batch, dtype, img_hw, scale_factor, rescale, ws, s, w, t);
     if (!rc && e1) rc = ia::hip_status(hipEventRecord(e1, s));
@@ -383,8 +397,10 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
 int ia_profile_stage_events(void *begin, void *end)
 {
     if ((begin == nullptr) != (end == nullptr)) return IA_E_ARG;
-    g_stage_ev[0].store(begin, std::memory_order_release);
+    g_stage_ev[0].store(nullptr, std::memory_order_release);        // no call records a half-updated pair
     g_stage_ev[1].store(end, std::memory_order_release);
+    g_stage_bound.store(0, std::memory_order_release);              // the next stage call binds its stream
+    g_stage_ev[0].store(begin, std::memory_order_release);
     return 0;
 }
 

@@ -209,11 +209,87 @@ static int launch_rowmax_nhwc(const LevelTable &t, const ia_level_ptrs &p, int b
     return hip_status(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------
+// use_sigmoid_cls = False (reference iou_aware_retina_head.py:506-507,540-541): the class tensor
+// carries C + 1 channels per anchor, channel 0 = background; scores = softmax over all C + 1, fused
+// with the IoU prediction like the sigmoid scores (:531), the row maximum over the FOREGROUND
+// columns only.  Canonical arithmetic (the oracle restates the same sequence): m = max over the
+// C + 1 logits; s = sum of exp(x_c - m), added in class order; score_c = sqrt(exp(x_c - m) / s) *
+// sqrt(sigmoid(iou)).  Correctly rounded division, square root and the product with a value >= 0
+// are non-decreasing, so the maximum over c of score_c is the score of the largest exp(x_c - m).
+// None of the four IoU-aware configs takes this branch: one thread per anchor row, both memory
+// orders, no tuning -- a correct path, not a streaming kernel.
+struct SoftmaxRowArgs {
+    LevelTable t;
+    ia_level_ptrs p;
+    float *rowmax;
+    int32_t anchors_per_img;
+};
+
+template <typename T>
+__device__ __forceinline__ void softmax_row_stats(const T *x, size_t cs, int Cin, float &m, float &s, float &e_fg)
+{
+    m = -__builtin_inff();
+    for (int c = 0; c < Cin; ++c) {
+        const float v = load_f32<T>(x + (size_t)c * cs);
+        m = (m < v) ? v : m;
+    }
+    s = 0.0f; e_fg = 0.0f;
+    for (int c = 0; c < Cin; ++c) {
+        const float e = expf_(load_f32<T>(x + (size_t)c * cs) - m);
+        s = s + e;
+        if (c >= 1) e_fg = (e_fg < e) ? e : e_fg;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_rowscore_softmax(SoftmaxRowArgs a)
+{
+    const int l = (int)blockIdx.y % a.t.num_levels, b = (int)blockIdx.y / a.t.num_levels;
+    const int A = a.t.A, Cin = a.t.C + 1, HW = a.t.H[l] * a.t.W[l];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // position in the level's stored order
+    if (i >= (int64_t)HW * A) return;
+    const bool nhwc = a.t.layout == IA_LAYOUT_NHWC;
+    const int pos = nhwc ? (int)(i / A) : (int)(i % HW);
+    const int an = nhwc ? (int)(i % A) : (int)(i / HW);
+    const size_t row = ((size_t)b * HW + pos) * A + an;
+    const size_t cs = nhwc ? (size_t)1 : (size_t)HW;
+    const T *cls = static_cast<const T *>(a.p.cls[l]) + (nhwc ? row * Cin : ((size_t)b * A + an) * Cin * HW + pos);
+    const T *iou = static_cast<const T *>(a.p.iou[l]) + (nhwc ? row : ((size_t)b * A + an) * HW + pos);
+    float m, s, e;
+    softmax_row_stats<T>(cls, cs, Cin, m, s, e);
+    a.rowmax[(size_t)b * a.anchors_per_img + a.t.anchor_off[l] + i] =
+        __builtin_sqrtf(e / s) * sqrt_sigmoidf_(load_f32<T>(iou));
+}
+
+static int launch_rowscore_softmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
+                                   float *rowmax, hipStream_t s)
+{
+    SoftmaxRowArgs a;
+    a.t = t; a.p = p; a.rowmax = rowmax; a.anchors_per_img = t.anchor_off[t.num_levels];
+    int64_t nmax = 1;
+    for (int l = 0; l < t.num_levels; ++l) {
+        const int64_t n = t.anchor_off[l + 1] - t.anchor_off[l];
+        nmax = n > nmax ? n : nmax;
+    }
+    if ((int64_t)batch * t.num_levels > 65535) return IA_E_ARG;
+    const dim3 grid((unsigned)((nmax + 255) / 256), (unsigned)(batch * t.num_levels));
+    if (dtype == IA_F32) hipLaunchKernelGGL(k_rowscore_softmax<float>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_rowscore_softmax<uint16_t>, grid, dim3(256), 0, s, a);
+    return hip_status(hipGetLastError());
+}
+
 int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype, float *rowmax,
                   hipStream_t s, float *groupmax)
 {
     if (batch < 1 || !rowmax) return IA_E_ARG;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    if (t.softmax) {
+        // (group maxima, when wanted, are derived from the finished array by the caller:
+        // launch_groupmax -- this kernel does not emit them)
+        (void)groupmax;
+        return launch_rowscore_softmax(t, p, batch, dtype, rowmax, s);
+    }
     if (t.layout == IA_LAYOUT_NHWC)
         return launch_rowmax_nhwc(t, p, batch, dtype, rowmax, s, groupmax);
     const int tile = 64 * (dtype == IA_F32 ? Lane<float>::PPL : Lane<uint16_t>::PPL);
@@ -389,6 +465,42 @@ __global__ void __launch_bounds__(1024) k_gather_nhwc(GatherArgs a, int tpc)
     GPROF(5);
 }
 
+// softmax head (see k_rowscore_softmax): one thread per candidate, the C foreground scores from the
+// C + 1 logits of its row, class-major like the other gather kernels; both memory orders
+template <typename T>
+__global__ void __launch_bounds__(64) k_gather_softmax(GatherArgs a)
+{
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.R) return;
+    const int A = a.t.A, C = a.t.C, Cin = C + 1;
+    const LevelSel lv = level_of_candidate(a, r);
+    const int W = lv.W, HW = lv.H * W;
+    const int idx = a.cand_idx[(size_t)b * a.R + r];
+    const int pos = idx / A, an = idx - pos * A;
+    const bool nhwc = a.t.layout == IA_LAYOUT_NHWC;
+    const size_t cs = nhwc ? (size_t)1 : (size_t)HW;
+    const size_t row = ((size_t)b * HW + pos) * A + an;
+    const T *cls = static_cast<const T *>(lv.cls) + (nhwc ? row * Cin : ((size_t)b * A + an) * Cin * HW + pos);
+    const T *iou = static_cast<const T *>(lv.iou) + (nhwc ? row : ((size_t)b * A + an) * HW + pos);
+    const float sq_iou = sqrt_sigmoidf_(load_f32<T>(iou));
+    float m, s, e_fg;
+    softmax_row_stats<T>(cls, cs, Cin, m, s, e_fg);
+    float *so = a.scores_t + (size_t)b * C * a.Rs + r;
+    float best = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float sc = __builtin_sqrtf(expf_(load_f32<T>(cls + (size_t)(c + 1) * cs) - m) / s) * sq_iou;
+        so[(size_t)c * a.Rs] = sc;
+        best = (best < sc) ? sc : best;
+    }
+    if (a.best_score) a.best_score[(size_t)b * a.R + r] = best;
+    const T *reg = static_cast<const T *>(lv.reg) + (nhwc ? row * 4 : ((size_t)b * A + an) * 4 * HW + pos);
+    const float *ba = a.ba.v[lv.l][an];
+    reinterpret_cast<float4 *>(a.boxes)[(size_t)b * a.R + r] =
+        decode_box(a, b, ba[0], ba[1], ba[2], ba[3], W, lv.stride, pos, load_f32<T>(reg), load_f32<T>(reg + cs),
+                   load_f32<T>(reg + 2 * cs), load_f32<T>(reg + 3 * cs));
+}
+
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,
@@ -403,6 +515,12 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
     a.boxes = boxes; a.scores_t = scores_t; a.best_score = best_score;
     a.R = t.cand_off[t.num_levels]; a.Rs = Rs; a.rescale = rescale;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
+    if (t.softmax) {
+        const dim3 grid((unsigned)((a.R + 63) / 64), (unsigned)batch);
+        if (dtype == IA_F32) hipLaunchKernelGGL(k_gather_softmax<float>, grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(k_gather_softmax<uint16_t>, grid, dim3(64), 0, s, a);
+        return hip_status(hipGetLastError());
+    }
     const int esz = dtype == IA_F32 ? 4 : 2;
     if (t.layout == IA_LAYOUT_NHWC && (t.C * esz) % 16 == 0 && t.C * esz / 16 <= kMaxVpr) {
         bool aligned = true;

@@ -697,6 +697,7 @@ static int fill_levels(const ia_head_geom *g, int B, HLLevels &lv)
     if (g->num_levels < 1 || g->num_levels > IA_MAX_LEVELS) return IA_E_ARG;
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS || g->num_classes < 1) return IA_E_ARG;
     if (g->layout != IA_LAYOUT_NCHW) return IA_E_ARG;            // training kernels: NCHW only
+    if (g->cls_activation != IA_CLS_SIGMOID) return IA_E_ARG;    // sigmoid focal loss only
     lv.L = g->num_levels; lv.B = B; lv.A = g->num_anchors; lv.C = g->num_classes;
     for (int l = 0; l < IA_MAX_LEVELS; ++l) {
         const bool on = l < lv.L;
@@ -895,6 +896,7 @@ static int fill_levels_nhwc(const ia_head_geom *g, int B, NhwcLevels &lv)
     if (g->num_anchors < 1 || g->num_anchors > IA_MAX_ANCHORS || g->num_classes < 4 ||
         (g->num_classes & 3))
         return IA_E_ARG;                                  // class quads: C % 4 == 0
+    if (g->cls_activation != IA_CLS_SIGMOID) return IA_E_ARG;    // sigmoid focal loss only
     if ((int64_t)g->num_anchors * (g->num_classes / 4) > 8192) return IA_E_ARG;   // float-reciprocal division
     lv.L = g->num_levels; lv.B = B; lv.A = g->num_anchors; lv.C = g->num_classes;
     int64_t foff = 0, boff = 0;

@@ -9,6 +9,7 @@ namespace ia {
 // per-level scalars used by kernels that do not need the base anchors
 struct LevelTable {
     int32_t num_levels, A, C, nms_pre, layout;
+    int32_t softmax;                         // IA_CLS_SOFTMAX: class tensors carry C + 1 channels per anchor
     int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], stride[IA_MAX_LEVELS];
     int32_t anchor_off[IA_MAX_LEVELS + 1];   // prefix of N_l   (anchors per image)
     int32_t cand_off[IA_MAX_LEVELS + 1];     // prefix of k_l   (candidates per image)
@@ -25,7 +26,9 @@ inline int make_level_table(const ia_head_geom *g, LevelTable &t)
     if (g->num_classes < 1 || g->num_classes > 4096) return IA_E_ARG;
     if (g->nms_pre > IA_MAX_NMS_PRE) return IA_E_LIMIT_NMS_PRE;
     if (g->layout != IA_LAYOUT_NCHW && g->layout != IA_LAYOUT_NHWC) return IA_E_ARG;
+    if (g->cls_activation != IA_CLS_SIGMOID && g->cls_activation != IA_CLS_SOFTMAX) return IA_E_ARG;
     t.layout = g->layout;
+    t.softmax = g->cls_activation == IA_CLS_SOFTMAX ? 1 : 0;
     t.num_levels = g->num_levels; t.A = g->num_anchors; t.C = g->num_classes; t.nms_pre = g->nms_pre;
     t.anchor_off[0] = t.cand_off[0] = t.tile_off[0] = 0;
     for (int l = 0; l < IA_MAX_LEVELS; ++l) {
@@ -116,6 +119,9 @@ int launch_rowmax(const LevelTable &t, const ia_level_ptrs &p, int batch, int dt
 size_t select_workspace_bytes(const LevelTable &t, int batch);
 // where launch_rowmax has to put the group maxima inside the select workspace
 float *select_workspace_groupmax(const LevelTable &t, int batch, void *workspace);
+// group maxima of the filtered levels derived from a complete row-max array (what launch_select does
+// itself when have_groups is false); for producers that do not emit them (softmax row scores)
+int launch_groupmax(const LevelTable &t, const float *rowmax, int batch, void *workspace, hipStream_t s);
 // byte offset (inside the select workspace) of the fused launch's status word: 0 = fine,
 // 1 = a filter workgroup gave up waiting, 2 = arrival counters found above their maximum
 size_t select_workspace_status_offset(const LevelTable &t, int batch);

@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(kFilterThreads) k_sel_filter(SelArgs a)
 // selects from the row maxima of the whole level instead of the candidate lists: the result is the
 // same detections, only slower; status[1] counts such calls (telemetry, ops.get_bboxes_status).
 constexpr uint32_t kSpinLimit = 1u << 21;
-static uint32_t g_spin_limit = kSpinLimit;            // ia_debug_fused_spin_limit (tests)
+static std::atomic<uint32_t> g_spin_limit{kSpinLimit};   // ia_debug_fused_spin_limit (tests)
 static std::atomic<uint32_t> g_fused_calls{0};
 
 // Four / eight L1-bypassing loads in flight per lane (agent-scope atomic loads are issued one at a
@@ -585,17 +585,20 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
     const uint32_t n = (uint32_t)(a.t.anchor_off[l + 1] - a.t.anchor_off[l]);
     const uint32_t k = (uint32_t)(a.t.cand_off[l + 1] - a.t.cand_off[l]);
     int32_t *out = a.cand_idx + (size_t)b * a.cands_per_img + a.t.cand_off[l];
+    // a filter workgroup of THIS call timed out: its candidate slice cannot be trusted; the row
+    // maxima are complete (kernel boundary), so the level is selected from them like a dense one
+    uint32_t *status = a.chunk_count + (size_t)a.batch * a.total_chunks;
+    const bool any_timeout = a.call_id != 0u &&
+                             __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.call_id;
+    // telemetry (status[1] = calls that fell back): counted by the first workgroup whatever ITS
+    // level is -- level 0 need not be a filtered one -- and before the k == n return
+    if (any_timeout && l == 0 && b == 0 && tid == 0) atomicAdd(status + 1, 1u);
     if (k == n) {
         for (uint32_t i = tid; i < n; i += nt) out[i] = (int32_t)i;
         return;
     }
     const bool in_plan = a.plan.grp[l] != 0;
-    // a filter workgroup of THIS call timed out: its candidate slice cannot be trusted; the row
-    // maxima are complete (kernel boundary), so the level is selected from them like a dense one
-    uint32_t *status = a.chunk_count + (size_t)a.batch * a.total_chunks;
-    const bool timed_out = a.call_id != 0u && in_plan &&
-                           __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.call_id;
-    if (timed_out && l == 0 && b == 0 && tid == 0) atomicAdd(status + 1, 1u);
+    const bool timed_out = any_timeout && in_plan;
     const bool filtered = in_plan && !timed_out;
     if (in_plan && a.t.layout == IA_LAYOUT_NHWC) {
         // state of the fused launch (k_rowmax_filter_nhwc) back to zero: the segment's group words
@@ -847,7 +850,7 @@ static int prepare_select(const LevelTable &t, const float *rowmax, int batch, i
     a.anchors_per_img = t.anchor_off[t.num_levels];
     a.cands_per_img = t.cand_off[t.num_levels];
     a.total_chunks = a.plan.chunk_off[IA_MAX_LEVELS];
-    a.call_id = 0; a.spin_limit = g_spin_limit;
+    a.call_id = 0; a.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
     // LDS of the final kernel: sel (next_pow2 of the largest k) + staged candidates
     uint32_t kmax = 1;
     for (int l = 0; l < t.num_levels; ++l) {
@@ -903,6 +906,22 @@ int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *
     return hip_status(hipGetLastError());
 }
 
+int launch_groupmax(const LevelTable &t, const float *rowmax, int batch, void *workspace, hipStream_t s)
+{
+    SelArgs a;
+    uint32_t p_max;
+    size_t dyn;
+    int32_t dummy = 0;
+    int rc = prepare_select(t, rowmax, batch, &dummy, workspace, a, p_max, dyn);     // cand_idx is not touched
+    if (rc) return rc;
+    if (a.total_chunks > 0) {
+        hipLaunchKernelGGL(k_sel_groupmax, dim3((unsigned)((a.plan.goff[IA_MAX_LEVELS] + 255) / 256)),
+                           dim3(256), 0, s, a, const_cast<uint32_t *>(a.groupmax));
+        rc = hip_status(hipGetLastError());
+    }
+    return rc;
+}
+
 // ia_get_bboxes / ia_decode_stage: row-max + top-k.  Channels-last heads with filtered levels take
 // the fused launch (k_rowmax_filter_nhwc) + k_sel_final; everything else the separate kernels.
 // `workspace` (select workspace) must have been zeroed once by its owner (seg_done).
@@ -921,6 +940,11 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
         const char *e = getenv("IA_FUSED_ROWMAX_FILTER");
         return !(e && e[0] == '0');
     }();
+    if (t.softmax) {            // softmax row scores (decode.hip), then the separate selection kernels
+        rc = launch_rowmax(t, p, batch, dtype, rowmax, s);
+        if (rc) return rc;
+        return launch_select(t, rowmax, batch, cand_idx, workspace, s, false);
+    }
     bool fused = allow_fused && t.layout == IA_LAYOUT_NHWC && a.total_chunks > 0 && t.C % ppl == 0 &&
                  t.C / ppl <= kMaxVpr;
     for (int l = 0; l < t.num_levels && fused; ++l) fused = (((uintptr_t)p.cls[l] & 15u) == 0);
@@ -1006,6 +1030,7 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
  * once, i.e. forces the fallback of k_sel_final. */
 extern "C" int ia_debug_fused_spin_limit(int64_t limit)
 {
-    ia::g_spin_limit = limit < 0 ? ia::kSpinLimit : (limit > 0xffffffffLL ? 0xffffffffu : (uint32_t)limit);
+    ia::g_spin_limit.store(limit < 0 ? ia::kSpinLimit : (limit > 0xffffffffLL ? 0xffffffffu : (uint32_t)limit),
+                           std::memory_order_relaxed);
     return 0;
 }

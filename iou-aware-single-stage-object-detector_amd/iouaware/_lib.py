@@ -14,6 +14,7 @@ IA_MAX_CANDIDATES = 8192
 IA_MAX_PER_IMG = 1024
 IA_F32, IA_BF16, IA_F16, IA_F64 = 0, 1, 2, 3
 IA_LAYOUT_NCHW, IA_LAYOUT_NHWC = 0, 1
+IA_CLS_SIGMOID, IA_CLS_SOFTMAX = 0, 1
 IA_LOSS_SLOTS = 64
 IA_MAX_TARGET_BATCH = 16
 
@@ -27,7 +28,8 @@ class HeadGeom(C.Structure):
                 ('H', C.c_int32 * IA_MAX_LEVELS), ('W', C.c_int32 * IA_MAX_LEVELS),
                 ('stride', C.c_int32 * IA_MAX_LEVELS),
                 ('base_anchors', ((C.c_float * 4) * IA_MAX_ANCHORS) * IA_MAX_LEVELS),
-                ('means', C.c_float * 4), ('stds', C.c_float * 4), ('layout', C.c_int32)]
+                ('means', C.c_float * 4), ('stds', C.c_float * 4), ('layout', C.c_int32),
+                ('cls_activation', C.c_int32)]
 
 
 class LevelPtrs(C.Structure):

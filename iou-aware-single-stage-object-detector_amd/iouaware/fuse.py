@@ -193,6 +193,14 @@ def _chain_ok(blk, nxt, x):
         and x.is_contiguous(memory_format=torch.channels_last)
 
 
+def _has_hooks(m):
+    """forward / forward-pre hooks on the module (or registered globally): a chained block is run by
+    _bottleneck_run directly, not through nn.Module.__call__, so its hooks would not fire"""
+    import torch.nn.modules.module as tm
+    return bool(m._forward_hooks or m._forward_pre_hooks or tm._global_forward_hooks
+                or tm._global_forward_pre_hooks)
+
+
 def _layer_forward(self, x):
     """a residual stage (nn.Sequential of bottlenecks, resnet.py:106-123): the blocks one after the
     other, and where two consecutive blocks allow it (stage 1 at the benchmark sizes) the boundary
@@ -203,8 +211,11 @@ def _layer_forward(self, x):
     h1 = None
     for i, blk in enumerate(blocks):
         nb = blocks[i + 1] if i + 1 < len(blocks) else None
-        chain = nb is not None and x.dtype == torch.float32 and _chain_ok(blk, nb, x) \
-            and _fast(blk, x) and _fast(nb, x) and _chain_ok(blk, nb, x)     # (a re-fold replaces the dicts)
+        # (_fast(nb, .) looks at dtype / device / memory format only -- block i + 1 receives a tensor
+        # with the same three as x; the second _chain_ok: a re-fold inside _fast replaces the dicts.
+        # Blocks with hooks are never bypassed: feature taps and profilers keep firing)
+        chain = nb is not None and x.dtype == torch.float32 and not _has_hooks(blk) and not _has_hooks(nb) \
+            and _chain_ok(blk, nb, x) and _fast(blk, x) and _fast(nb, x) and _chain_ok(blk, nb, x)
         if chain or h1 is not None:
             x, h1 = _bottleneck_run(blk, x, h1=h1, nxt=nb._ia_fused if chain else None)
         else:

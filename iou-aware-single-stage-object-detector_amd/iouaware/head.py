@@ -102,8 +102,11 @@ class AnchorHead(nn.Module):
         g = self._geom_cache.get(key)
         if g is None:
             base = np.stack([gen.base_anchors.numpy() for gen in self.anchor_generators])
-            g = ops.HeadGeometry(key[0], self.anchor_strides, base, self.cls_out_channels,
-                                 nms_pre=nms_pre, means=self.target_means, stds=self.target_stds)
+            # score columns = foreground classes; a softmax head (use_sigmoid_cls=False) carries
+            # num_classes channels per anchor with the background in channel 0 (:506-507,540-541)
+            g = ops.HeadGeometry(key[0], self.anchor_strides, base, self.num_classes - 1,
+                                 nms_pre=nms_pre, means=self.target_means, stds=self.target_stds,
+                                 softmax=not self.use_sigmoid_cls)
             self._geom_cache[key] = g
         return g
 
@@ -179,8 +182,6 @@ class IoUawareRetinaHead(AnchorHead):
         rows (B,max) int32, num (B) int32 -- no host synchronisation."""
         if not len(cls_scores) == len(bbox_preds) == len(iou_preds) == len(self.anchor_generators):
             raise AssertionError('level count mismatch')
-        if not self.use_sigmoid_cls:
-            raise NotImplementedError('softmax classification is outside the IoU-aware configs')
         nms_cfg = dict(cfg.nms)
         nms_type = nms_cfg.pop('type', 'nms')
         if nms_type not in ('nms', 'soft_nms'):

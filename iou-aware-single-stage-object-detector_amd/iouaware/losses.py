@@ -53,6 +53,38 @@ class FocalLoss(nn.Module):
 
 
 @LOSSES.register_module
+class CrossEntropyLoss(nn.Module):
+    """The loss a softmax-classification head names (`loss_cls=dict(type='CrossEntropyLoss',
+    use_sigmoid=False)`, reference mmdet/models/losses/cross_entropy_loss.py:9-31 with
+    core/loss/losses.py:19-26,141-149).  Host-side torch arithmetic: none of the IoU-aware
+    configs trains with it; it exists so that a use_sigmoid_cls=False head can be built (its
+    INFERENCE branch, iou_aware_retina_head.py:506-507,540-541, runs on the HIP path).
+    Returns a (1,)-shaped tensor = loss_weight * weighted sum / avg_factor."""
+
+    def __init__(self, use_sigmoid=False, use_mask=False, loss_weight=1.0):
+        super(CrossEntropyLoss, self).__init__()
+        if use_mask:
+            raise NotImplementedError('mask cross entropy belongs to the mask heads (out of scope)')
+        self.use_sigmoid, self.use_mask, self.loss_weight = use_sigmoid, use_mask, loss_weight
+
+    def forward(self, cls_score, label, label_weight, avg_factor=None, **kwargs):
+        import torch.nn.functional as F
+        if avg_factor is None:
+            avg_factor = max(float((label_weight > 0).sum().item()), 1.0)
+        if self.use_sigmoid:
+            if cls_score.dim() != label.dim():            # integer labels 0..C -> one-hot over C columns
+                hot = torch.zeros_like(cls_score)
+                fg = torch.nonzero(label >= 1).flatten()
+                hot[fg, label[fg] - 1] = 1.0
+                label, label_weight = hot, label_weight.reshape(-1, 1).expand_as(cls_score)
+            total = F.binary_cross_entropy_with_logits(cls_score, label.to(cls_score.dtype),
+                                                       label_weight.to(cls_score.dtype), reduction='sum')
+        else:
+            total = (F.cross_entropy(cls_score, label, reduction='none') * label_weight).sum()
+        return self.loss_weight * total.reshape(1) / avg_factor
+
+
+@LOSSES.register_module
 class SmoothL1Loss(nn.Module):
     def __init__(self, beta=1.0, loss_weight=1.0):
         super(SmoothL1Loss, self).__init__()

@@ -132,6 +132,7 @@ def _multiclass_nms_per_class(multi_bboxes, multi_scores, score_thr, nms_type, c
     max_num = -1: always, and the lowest survivor is dropped -- the reference's `inds[:-1]`).
     The unbounded route behind the batched kernels' capacities."""
     num_classes = multi_scores.shape[1]
+    max_num = -1 if max_num is None else int(max_num)       # like the batched route (ADVICE r4)
     bboxes, labels = [], []
     for i in range(1, num_classes):
         cls_inds = multi_scores[:, i] > score_thr

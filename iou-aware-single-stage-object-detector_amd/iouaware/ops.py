@@ -43,7 +43,10 @@ class HeadGeometry(object):
     (fills the C struct ia_head_geom)."""
 
     def __init__(self, featmap_sizes, strides, base_anchors, num_classes, nms_pre=-1,
-                 means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+                 means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), softmax=False):
+        """num_classes: foreground classes C (the score columns).  softmax=True: the head's
+        use_sigmoid_cls=False branch (iou_aware_retina_head.py:506-507,540-541): the class tensors
+        carry A * (C + 1) channels, channel 0 of an anchor = background."""
         base = np.asarray(base_anchors, dtype=np.float32)
         L, A = base.shape[0], base.shape[1]
         if L != len(featmap_sizes) or L != len(strides):
@@ -59,8 +62,11 @@ class HeadGeometry(object):
                     g.base_anchors[l][a][k] = float(base[l, a, k])
         for k in range(4):
             g.means[k], g.stds[k] = float(means[k]), float(stds[k])
+        g.cls_activation = _lib.IA_CLS_SOFTMAX if softmax else _lib.IA_CLS_SIGMOID
         self.struct = g
         self.L, self.A, self.C = L, A, int(num_classes)
+        self.softmax = bool(softmax)
+        self.Cin = self.C + 1 if softmax else self.C          # class channels per anchor
         self.featmap_sizes = [tuple(int(v) for v in s) for s in featmap_sizes]
         self.strides = [int(s) for s in strides]
         n, r, rs = C.c_int32(), C.c_int32(), C.c_int32()
@@ -72,7 +78,7 @@ class HeadGeometry(object):
         self.layout = _lib.IA_LAYOUT_NCHW
         self._twin = None
         # what the workspace carve-up depends on (besides batch, layout and dtype)
-        self.key = (tuple(self.featmap_sizes), A, int(num_classes), int(nms_pre))
+        self.key = (tuple(self.featmap_sizes), A, int(num_classes), int(nms_pre), bool(softmax))
 
     def ref(self):
         return C.byref(self.struct)
@@ -109,7 +115,7 @@ def to_nchw(t):
 def _nhwc_ok(geom, tensors):
     """channels-last head outputs are consumed in place (no transposes) when every tensor is
     channels-last contiguous and a class row is a whole number (<= 32) of 16-byte vectors"""
-    row = geom.C * tensors[0].element_size()
+    row = geom.Cin * tensors[0].element_size()
     if row % 16 != 0 or row > 512:
         return False
     if all(t.is_contiguous() for t in tensors):
@@ -130,7 +136,7 @@ def level_ptrs(geom, cls, reg, iou):
     geom = geom.with_layout(_lib.IA_LAYOUT_NHWC if nhwc else _lib.IA_LAYOUT_NCHW)
     for l in range(geom.L):
         h, w = geom.featmap_sizes[l]
-        for name, t, ch in (('cls_score', cls[l], geom.A * geom.C), ('bbox_pred', reg[l], geom.A * 4),
+        for name, t, ch in (('cls_score', cls[l], geom.A * geom.Cin), ('bbox_pred', reg[l], geom.A * 4),
                             ('iou_pred', iou[l], geom.A)):
             _require_gpu(t, name)
             if tuple(t.shape) != (B, ch, h, w):

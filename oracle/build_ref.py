@@ -51,12 +51,17 @@ def build(force=False):
 
 
 SOFT_SRC = '/root/reference/mmdet/ops/nms/src/soft_nms_cpu.pyx'
-SOFT_OUT = os.path.join(OUT_DIR, 'soft_nms_cpu.so')
+# NOT under oracle/_ref/: that directory travels to the GPU box, and the reference's Python (the
+# .pyx is Python-side source) never travels in any form.  oracle/_ref_local/ is listed in
+# .gitignore AND .gpurunignore; the committed tests/golden/soft_nms.npz is the pin on the GPU box.
+SOFT_DIR = os.path.join(HERE, '_ref_local')
+SOFT_OUT = os.path.join(SOFT_DIR, 'soft_nms_cpu.so')
 
 
 def build_soft(force=False):
-    """The reference's own soft-NMS (Cython) -> oracle/_ref/soft_nms_cpu.so.  The .pyx is
-    translated from where it lies; the generated C only exists in a temporary directory."""
+    """The reference's own soft-NMS (Cython) -> oracle/_ref_local/soft_nms_cpu.so (build container
+    only, never shipped).  The .pyx is translated from where it lies; the generated C only exists
+    in a temporary directory."""
     if not os.path.exists(SOFT_SRC):
         return None
     if os.path.exists(SOFT_OUT) and not force and \
@@ -64,7 +69,10 @@ def build_soft(force=False):
         return SOFT_OUT
     import tempfile
     import numpy
-    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(SOFT_DIR, exist_ok=True)
+    stale = os.path.join(OUT_DIR, 'soft_nms_cpu.so')        # location of rounds <= 4
+    if os.path.exists(stale):
+        os.remove(stale)
     with tempfile.TemporaryDirectory() as tmp:
         c_file = os.path.join(tmp, 'soft_nms_cpu.c')
         subprocess.run([sys.executable, '-m', 'cython', '-3', SOFT_SRC, '-o', c_file], check=True,

@@ -108,8 +108,10 @@ def head_base_anchors(strides, octave_base_scale=4, scales_per_octave=3,
 
 def get_bboxes_single(cls, reg, iou, strides, base_anchors, img_shape, scale_factor, rescale,
                       nms_pre=1000, score_thr=0.05, iou_thr=0.5, max_per_img=100,
-                      means=(0, 0, 0, 0), stds=(1, 1, 1, 1), C_cls=80):
-    """cls/reg/iou: lists (one per level) of (ch,H,W) fp32 arrays of ONE image."""
+                      means=(0, 0, 0, 0), stds=(1, 1, 1, 1), C_cls=80, softmax=False):
+    """cls/reg/iou: lists (one per level) of (ch,H,W) fp32 arrays of ONE image.
+    softmax=True: use_sigmoid_cls=False (iou_aware_retina_head.py:506-507,540-541): cls has
+    A * (C_cls + 1) channels, channel 0 of an anchor = background; C_cls foreground columns."""
     L = len(cls)
     cls = [_f(x) for x in cls]
     reg = [_f(x) for x in reg]
@@ -137,14 +139,15 @@ def get_bboxes_single(cls, reg, iou, strides, base_anchors, img_shape, scale_fac
     dl = np.zeros(max(mp, 1), np.int32)
     dr = np.zeros(max(mp, 1), np.int32)
     Rout = C.c_int32(0)
-    fn = lib().ia_o_get_bboxes_single
+    assert all(x.shape[0] == A * (C_cls + (1 if softmax else 0)) for x in cls)
+    fn = lib().ia_o_get_bboxes_single_ex
     fn.restype = C.c_int
     nd = fn(L, PP(*[_fp(x) for x in cls]), PP(*[_fp(x) for x in reg]),
             PP(*[_fp(x) for x in iou]), _ip(Hs), _ip(Ws), _ip(st), _fp(base), A, C_cls,
             _fp(means), _fp(stds), C.c_float(img_shape[0]), C.c_float(img_shape[1]), _fp(sf),
             int(bool(rescale)), int(nms_pre), C.c_float(score_thr), C.c_float(iou_thr),
             int(max_per_img), _fp(rowmax), _ip(topk), _fp(boxes), _fp(scores), _ip(kc), _ip(kr),
-            _fp(db), _ip(dl), _ip(dr), C.byref(Rout))
+            _fp(db), _ip(dl), _ip(dr), C.byref(Rout), int(bool(softmax)))
     assert Rout.value == R
     lvl_off = np.cumsum([0] + Nl)
     cand_off = np.cumsum([0] + kl)

@@ -297,6 +297,33 @@ def gen_get_bboxes():
         save('get_bboxes_full_%s' % kind, **out)
 
 
+def gen_get_bboxes_softmax():
+    """use_sigmoid_cls = False (iou_aware_retina_head.py:506-507,540-541): the reference head built
+    with a softmax classification loss -- cls_out_channels = 81, scores = softmax, row maximum over
+    scores[:, 1:], no background padding in front of multiclass_nms (:556-558)."""
+    kw = dict(HEAD_KW)
+    kw['loss_cls'] = dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)
+    head = IoUawareRetinaHead(**kw)
+    assert not head.use_sigmoid_cls and head.cls_out_channels == 81
+    cfg = ref_shim.to_cfg(dict(nms_pre=300, min_bbox_size=0, score_thr=0.05,
+                               nms=dict(type='nms', iou_thr=0.5), max_per_img=100))
+    seed, B, ih, iw, ph, pw = 707, 2, 120, 157, 128, 160
+    cls, reg, iou = synth.head_outputs_softmax(seed, B, ph, pw)
+    metas = [synth.img_meta(ih, iw, ph, pw, 1.0), synth.img_meta(ih, iw, ph, pw, 1.6)]
+    res = run_ref_get_bboxes(head, cls, reg, iou, metas, cfg, True)
+    out = dict(seed=seed, batch=B, img=np.array([ih, iw, ph, pw]), kind='softmax', nms_pre=300,
+               score_thr=np.float32(0.05), iou_thr=np.float32(0.5), max_per_img=100,
+               scale_factors=np.array([1.0, 1.6], np.float32), rescale=1,
+               checksum=synth.checksum(cls + reg + iou))
+    for b, r in enumerate(res):
+        for k, v in r.items():
+            out['%s_%d' % (k, b)] = v
+        print('softmax img', b, 'dets', r['det_bboxes'].shape, 'into-nms',
+              int((r['mlvl_scores'] > 0.05).sum()), 'kept', int(r['keep_count'].sum()),
+              'topk margins', r['topk_margin'])
+    save('get_bboxes_softmax', **out)
+
+
 # ---------------------------------------------------------------- soft-NMS (SURVEY 8f.4)
 def gen_soft_nms():
     rs = np.random.RandomState(23)
@@ -924,7 +951,7 @@ def gen_model():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['anchors', 'delta2bbox', 'nms', 'get_bboxes', 'soft_nms', 'losses', 'losses_balanced', 'model', 'e2e', 'focal_op', 'train_e2e', 'e2e_backbones', 'mnms_quirk', 'get_bboxes_vecscale', 'nms_f64', 'mnms_big',
-                             'losses_mixed_pad']
+                             'losses_mixed_pad', 'get_bboxes_softmax']
     for w in which:
         if ':' in w:                          # e.g. e2e_backbones:r101_full,x101_64x4d_full
             w, only = w.split(':')

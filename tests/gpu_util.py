@@ -16,7 +16,7 @@ def product_base_anchors(strides=synth.STRIDES, octave_base_scale=4, scales_per_
                      for s in strides])
 
 
-def geometry(pad_h, pad_w, nms_pre, means=(0, 0, 0, 0), stds=(1, 1, 1, 1)):
+def geometry(pad_h, pad_w, nms_pre, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), softmax=False):
     """-> (HIP geometry built from the product's anchor generator, the ORACLE's base anchors for
     the checker side); the two generators must agree bit for bit"""
     import oracle
@@ -26,7 +26,7 @@ def geometry(pad_h, pad_w, nms_pre, means=(0, 0, 0, 0), stds=(1, 1, 1, 1)):
     base = product_base_anchors()
     assert base.dtype == np.float32 and np.array_equal(base, base_oracle)
     return ops.HeadGeometry(sizes, synth.STRIDES, base, synth.C, nms_pre=nms_pre, means=means,
-                            stds=stds), base_oracle
+                            stds=stds, softmax=softmax), base_oracle
 
 
 def to_dev(arrs, dtype=torch.float32):

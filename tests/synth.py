@@ -59,6 +59,21 @@ def head_outputs(seed, batch, pad_h, pad_w, kind='A', strides=STRIDES):
     return cls, reg, iou
 
 
+def head_outputs_softmax(seed, batch, pad_h, pad_w, strides=STRIDES):
+    """head outputs of a use_sigmoid_cls=False head (iou_aware_retina_head.py:506-507): the class
+    tensor carries A * (C + 1) channels, channel 0 of an anchor = background (a +3 logit bias,
+    like a trained softmax head: most anchors are background).  -> cls[L], reg[L], iou[L]"""
+    rs = np.random.RandomState(seed)
+    cls, reg, iou = [], [], []
+    for (h, w) in level_shapes(pad_h, pad_w, strides):
+        c = (rs.standard_normal((batch, A, C + 1, h, w)) * 2.5).astype(np.float32)
+        c[:, :, 0] += np.float32(3.0)
+        cls.append(np.ascontiguousarray(c.reshape(batch, A * (C + 1), h, w)))
+        reg.append((rs.standard_normal((batch, A * 4, h, w)) * 0.5).astype(np.float32))
+        iou.append((rs.standard_normal((batch, A, h, w)) * 1.5).astype(np.float32))
+    return cls, reg, iou
+
+
 def checksum(arrays):
     c = 0
     for a in arrays:

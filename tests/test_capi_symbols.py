@@ -45,8 +45,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from iouaware import _lib
-    # 4 ints + 3*8 ints + 8*16*4 floats + 8 floats + layout
-    assert ctypes.sizeof(_lib.HeadGeom) == 4 * 4 + 3 * 8 * 4 + 8 * 16 * 4 * 4 + 8 * 4 + 4
+    # 4 ints + 3*8 ints + 8*16*4 floats + 8 floats + layout + cls_activation
+    assert ctypes.sizeof(_lib.HeadGeom) == 4 * 4 + 3 * 8 * 4 + 8 * 16 * 4 * 4 + 8 * 4 + 4 + 4
+    assert _lib.HeadGeom.cls_activation.offset == ctypes.sizeof(_lib.HeadGeom) - 4
     assert ctypes.sizeof(_lib.LevelPtrs) == 3 * 8 * 8
 
 

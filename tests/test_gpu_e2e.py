@@ -113,10 +113,10 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
     """Every reference detection without a counterpart within TOL must have a stated reason, or
     the test fails (round 2 accepted `matched >= total - 2 / - 5` without looking at WHICH ones):
       closer-to-truth  (`truth`: the same detector evaluated in fp64, per-class arrays) the
-                own detection is not farther from the fp64 evaluation than max(TOL, what the
-                reference's fp32 result is): |own - truth| <= max(TOL, |ref - truth|) in every
-                coordinate -- the deviation belongs to the reference's own fp32 rounding
-                (VERDICT r3 item 1b: triangulation instead of a widened band);
+                own detection is within TOL of the fp64 evaluation in every coordinate:
+                |own - truth| <= TOL -- the deviation from the reference belongs to the
+                reference's own fp32 rounding (triangulation instead of a
+                widened band; r4 item 5: the bound is TOL itself, not max(TOL, |ref - truth|));
       near-tol  a detection of the same class differs by at most `near` (2) x TOL in one
                 coordinate: the accumulated fp32 convolution error of ~60-110 layers touches
                 the tolerance;
@@ -145,7 +145,10 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
                 e_ref = _relerr(d, tj)
                 gj = g[int(np.argmin(_relerr(g, tj).max(1)))]
                 e_own = _relerr(gj, tj)
-                if e_ref.max() <= 10 * TOL and (e_own <= np.maximum(TOL, e_ref)).all():
+                # the own detection itself must be within TOL of the fp64 twin (not
+                # merely no farther than the reference is): the hatch only ever excuses the
+                # REFERENCE's fp32 rounding, never this build's
+                if e_ref.max() <= 10 * TOL and (e_own <= TOL).all():
                     lines.append('class %d score %.4f: own detection off the reference by %.2f x TOL, off the fp64 '
                                  'evaluation by %.2f x TOL; the REFERENCE is off its own fp64 evaluation by %.2f x '
                                  'TOL (closer-to-truth)' % (c, d[4], near / TOL, e_own.max() / TOL, e_ref.max() / TOL))
@@ -177,12 +180,27 @@ def _truth_worst(truth, dets):
 
 
 _REPORT = []
+_HATCHES = []          # (fixture, path / image, number of explained misses): printed with the report
+
+
+def _hatch_budget(tag, why, allowed):
+    """the number of EXPLAINED misses is capped per fixture -- 0 for the R-50
+    fixtures (BASELINE configs 1 / 2), at most 1 for the ~110-layer backbones -- so the hatch
+    count cannot grow silently; the count goes into the parity report."""
+    _HATCHES.append((tag, len(why)))
+    assert len(why) <= allowed, '%s: %d explained misses, %d allowed: %s' % (tag, len(why), allowed, why)
+
 
 
 @pytest.fixture(scope='module', autouse=True)
 def _print_report():
     yield
     if _REPORT:
+        if _HATCHES:
+            _REPORT.append('tolerance hatches used (explained misses; cap 0 on the R-50 fixtures, 1 per '
+                           'fixture on the deeper backbones): %d in total over %d comparisons -- %s'
+                           % (sum(n for _, n in _HATCHES), len(_HATCHES),
+                              ', '.join('%s: %d' % h for h in _HATCHES if h[1]) or 'none'))
         print('\n[e2e parity report]')
         for line in _REPORT:
             print('  ' + line)
@@ -261,8 +279,9 @@ def test_image_to_detections_matches_reference(golden_dir, name, path):
         _REPORT.append('      %s %s: %s' % (name, path, line))
     assert bad == 0, why
     assert matched + len(why) == total
-    near_cut = sum('near-cut' in w for w in why)
-    assert same_ids >= len(theirs) - near_cut, (same_ids, len(theirs), why)
+    # configs 1 / 2 (R-50): 100 / 100 within 1e-4 with NO hatch, asserted
+    _hatch_budget('r50 %s %s' % (name, path), why, 0)
+    assert same_ids == len(theirs), (same_ids, len(theirs))
 
 
 def test_reference_call_signature_variants(golden_dir):
@@ -391,6 +410,7 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
         for line in why:
             _REPORT.append('      %s image %d: %s' % (name, b, line))
         assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
+        _hatch_budget('%s image %d (bench path vs plain modules)' % (name, b), why, 1)
 
 
 @pytest.mark.parametrize('path', ['module', 'winograd'])
@@ -458,6 +478,7 @@ def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
     for line in why:
         _REPORT.append('      %s %s: %s' % (name, path, line))
     assert total == 100 and bad == 0 and matched + len(why) == total, (matched, total, why)
+    _hatch_budget('%s %s (vs the reference)' % (name, path), why, 1)
     # (reported, not asserted: the distance of the product path from the fp64 evaluation.  The
     # north star's bar is the reference; on the 256x320 X-101-64x4d fixture one ill-conditioned
     # box -- exp(dw) on a 400 px anchor amplifies a 0.15 x TOL logit difference eightfold -- puts

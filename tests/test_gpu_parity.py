@@ -50,19 +50,20 @@ def test_device_math_is_bit_identical_to_oracle(ops, oracle_lib):
 
 # ------------------------------------------------------------------ stages
 def oracle_image(oracle_lib, cls, reg, iou, b, base, img_hw, sf, rescale, nms_pre, score_thr,
-                 iou_thr, max_per_img, means=(0, 0, 0, 0), stds=(1, 1, 1, 1)):
+                 iou_thr, max_per_img, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), softmax=False,
+                 C_cls=synth.C):
     return oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
                                         [x[b] for x in iou], synth.STRIDES, base, img_hw, sf,
                                         rescale, nms_pre, score_thr, iou_thr, max_per_img,
-                                        means=means, stds=stds)
+                                        means=means, stds=stds, softmax=softmax, C_cls=C_cls)
 
 
 def check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr,
                          iou_thr, max_per_img, dtype=torch.float32, means=(0, 0, 0, 0),
-                         stds=(1, 1, 1, 1)):
+                         stds=(1, 1, 1, 1), layouts=(True, False)):
     """both memory orders of the head outputs: NCHW (k_rowmax) and channels-last, consumed in
     place (k_rowmax_nhwc) -- every stage bit for bit against the oracle"""
-    for channels_last in (True, False):
+    for channels_last in layouts:
         out = _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, score_thr,
                             iou_thr, max_per_img, dtype, means, stds, channels_last)
     return out
@@ -75,7 +76,10 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
     if channels_last:
         dc, dr, di = [[t.contiguous(memory_format=torch.channels_last) for t in x]
                       for x in (dc, dr, di)]
-        assert ops.geometry_for(geom, dc, dr, di).layout == 1
+        # consumed in place when a class row is a whole number of 16-byte vectors (81 softmax
+        # channels are not: those heads are transposed to NCHW by ops.level_ptrs)
+        in_place = (geom.Cin * dc[0].element_size()) % 16 == 0
+        assert ops.geometry_for(geom, dc, dr, di).layout == (1 if in_place else 0)
     shapes = [m['img_shape'] for m in metas]
     sfs = [m['scale_factor'] for m in metas]
     dets, labels, rows, num, dbg = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale,
@@ -94,7 +98,8 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
     out = []
     for b in range(B):
         o = oracle_image(oracle_lib, cls, reg, iou, b, base, shapes[b][:2], sfs[b], rescale,
-                         geom.struct.nms_pre, score_thr, iou_thr, max_per_img, means, stds)
+                         geom.struct.nms_pre, score_thr, iou_thr, max_per_img, means, stds,
+                         softmax=geom.softmax, C_cls=geom.C)
         # device layout for NCHW heads: per level an (A, HW) block; channels-last heads and the
         # oracle: reference order p*A + a
         off = 0
@@ -125,16 +130,18 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
     return out
 
 
-@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale'])
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale', 'softmax'])
 def test_get_bboxes_vs_oracle_and_golden(ops, oracle_lib, golden_dir, name):
+    """'softmax': the use_sigmoid_cls=False branch (iou_aware_retina_head.py:506-507,540-541), 81
+    class channels per anchor, fixture from the reference head built with a softmax loss"""
     f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
     ih, iw, ph, pw = [int(v) for v in f['img']]
     B = int(f['batch'])
-    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    from test_oracle_golden import scale_factor_of, fixture_inputs
+    cls, reg, iou = fixture_inputs(f)
     assert synth.checksum(cls + reg + iou) == int(f['checksum'])
-    geom, base = G.geometry(ph, pw, int(f['nms_pre']))
+    geom, base = G.geometry(ph, pw, int(f['nms_pre']), softmax=name == 'softmax')
     # 'vecscale': the 4-vector scale_factor of a non-keep-ratio resize (transforms.py:33-38)
-    from test_oracle_golden import scale_factor_of
     metas = [synth.img_meta(ih, iw, ph, pw, scale_factor_of(f, b)) for b in range(B)]
     res = check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas,
                                bool(f['rescale']), float(f['score_thr']), float(f['iou_thr']),
@@ -146,6 +153,79 @@ def test_get_bboxes_vs_oracle_and_golden(ops, oracle_lib, golden_dir, name):
         assert np.array_equal(r['det_labels'], f['det_labels_%d' % b])
         assert np.array_equal(r['det_rows'], f['det_rows_%d' % b])
         assert G.close(r['det_bboxes'], f['det_bboxes_%d' % b], 1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_softmax_head_channels_last_in_place(ops, oracle_lib, dtype):
+    """softmax branch with 79 foreground classes: 80 class channels per anchor = whole 16-byte
+    vectors, so channels-last head outputs are consumed in place (the NHWC arm of
+    k_rowscore_softmax / k_gather_softmax); every stage bit for bit against the oracle, fp32 and
+    bf16 storage, plus the stage-wise C-ABI entries (grouped row-max -> top-k)"""
+    from iouaware import ops as iops
+    ph, pw, B, Cf = 320, 384, 2, 79          # P3: 40 x 48 x 9 = 17 280 anchors: a FILTERED level of the top-k
+    rs = np.random.RandomState(4242)
+    cls, reg, iou = [], [], []
+    for (h, w) in synth.level_shapes(ph, pw):
+        c = (rs.standard_normal((B, synth.A, Cf + 1, h, w)) * 2.5).astype(np.float32)
+        c[:, :, 0] += np.float32(2.0)
+        cls.append(np.ascontiguousarray(c.reshape(B, synth.A * (Cf + 1), h, w)))
+        reg.append((rs.standard_normal((B, synth.A * 4, h, w)) * 0.5).astype(np.float32))
+        iou.append((rs.standard_normal((B, synth.A, h, w)) * 1.5).astype(np.float32))
+    if dtype == torch.bfloat16:
+        cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
+    _, base = G.geometry(ph, pw, 300)
+    geom = iops.HeadGeometry(synth.level_shapes(ph, pw), synth.STRIDES, base, Cf, nms_pre=300,
+                             softmax=True)
+    assert geom.Cin == 80 and geom.softmax
+    metas = [synth.img_meta(310, 377, ph, pw, 1.0), synth.img_meta(310, 377, ph, pw, 1.6)]
+    check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, True, 0.05, 0.5, 100,
+                         dtype=dtype)
+    # stage entries: row scores (+ group maxima derived behind them) -> top-k, both orders
+    for channels_last in (True, False):
+        dc, dr, di = G.to_dev(cls, dtype), G.to_dev(reg, dtype), G.to_dev(iou, dtype)
+        if channels_last:
+            dc, dr, di = [[t.contiguous(memory_format=torch.channels_last) for t in x]
+                          for x in (dc, dr, di)]
+        g = iops.geometry_for(geom, dc, dr, di)
+        assert g.layout == (1 if channels_last else 0)
+        rowmax = iops.decode_fuse_rowmax(g, dc, dr, di)
+        cand = iops.select_topk(g, rowmax)
+        ws = iops.select_workspace(g, B, dc[0].device).zero_()
+        cand_grouped = iops.select_topk(g, iops.decode_fuse_rowmax(g, dc, dr, di, ws), ws)
+        assert torch.equal(cand, cand_grouped)
+        for b in range(B):
+            o = oracle_image(oracle_lib, cls, reg, iou, b, base, (310, 377), 1.0, True, 300, 0.05,
+                             0.5, 100, softmax=True, C_cls=Cf)
+            assert np.array_equal(cand[b].cpu().numpy(), o['topk_inds'])
+
+
+def test_softmax_head_module_matches_reference(golden_dir):
+    """IoUawareRetinaHead built with a softmax classification loss (use_sigmoid_cls=False):
+    81 class channels per anchor, get_bboxes against the reference head's own detections"""
+    from iouaware.head import IoUawareRetinaHead
+    from iouaware.config import ConfigDict
+    f = np.load(os.path.join(golden_dir, 'get_bboxes_softmax.npz'))
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    head = IoUawareRetinaHead(num_classes=81, in_channels=256, stacked_convs=4, feat_channels=256,
+                              octave_base_scale=4, scales_per_octave=3, anchor_ratios=[0.5, 1.0, 2.0],
+                              anchor_strides=[8, 16, 32, 64, 128],
+                              loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                              loss_bbox=dict(type='SmoothL1Loss', beta=0.11, loss_weight=1.0))
+    assert not head.use_sigmoid_cls and head.cls_out_channels == 81
+    assert head.retina_cls.out_channels == 9 * 81
+    cls, reg, iou = synth.head_outputs_softmax(int(f['seed']), int(f['batch']), ph, pw)
+    cfg = ConfigDict(dict(nms_pre=int(f['nms_pre']), min_bbox_size=0, score_thr=float(f['score_thr']),
+                          nms=dict(type='nms', iou_thr=float(f['iou_thr'])), max_per_img=int(f['max_per_img'])))
+    metas = [synth.img_meta(ih, iw, ph, pw, float(s)) for s in f['scale_factors']]
+    for channels_last in (False, True):
+        dev = [G.to_dev(x) for x in (cls, reg, iou)]
+        if channels_last:
+            dev = [[t.contiguous(memory_format=torch.channels_last) for t in x] for x in dev]
+        res = head.get_bboxes(dev[0], dev[1], dev[2], None, None, metas, cfg, True)
+        for b, (dets, labels) in enumerate(res):
+            assert labels.dtype == torch.int64
+            assert np.array_equal(labels.cpu().numpy(), f['det_labels_%d' % b])
+            assert G.close(dets.cpu().numpy(), f['det_bboxes_%d' % b], 1e-4)
 
 
 def test_heavy_ties_random_init_like(ops, oracle_lib):

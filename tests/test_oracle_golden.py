@@ -109,15 +109,24 @@ def run_oracle(oracle_lib, f, b, cls, reg, iou):
     return oracle_lib.get_bboxes_single(
         [x[b] for x in cls], [x[b] for x in reg], [x[b] for x in iou], synth.STRIDES, base,
         (ih, iw), scale_factor_of(f, b), bool(f['rescale']), int(f['nms_pre']),
-        float(f['score_thr']), float(f['iou_thr']), int(f['max_per_img']))
+        float(f['score_thr']), float(f['iou_thr']), int(f['max_per_img']),
+        softmax=str(f['kind']) == 'softmax')
 
 
-@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale'])
+def fixture_inputs(f):
+    """the synthetic head outputs a get_bboxes fixture was generated from"""
+    ih, iw, ph, pw = [int(v) for v in f['img']]
+    if str(f['kind']) == 'softmax':          # use_sigmoid_cls = False: 81 class channels per anchor
+        return synth.head_outputs_softmax(int(f['seed']), int(f['batch']), ph, pw)
+    return synth.head_outputs(int(f['seed']), int(f['batch']), ph, pw, str(f['kind']))
+
+
+@pytest.mark.parametrize('name', ['small', 'dense', 'full_A', 'full_C', 'vecscale', 'softmax'])
 def test_get_bboxes(oracle_lib, golden_dir, name):
     f = np.load(os.path.join(golden_dir, 'get_bboxes_%s.npz' % name))
     ih, iw, ph, pw = [int(v) for v in f['img']]
     B = int(f['batch'])
-    cls, reg, iou = synth.head_outputs(int(f['seed']), B, ph, pw, str(f['kind']))
+    cls, reg, iou = fixture_inputs(f)
     assert synth.checksum(cls + reg + iou) == int(f['checksum']), 'synthetic inputs drifted'
     for b in range(B):
         r = run_oracle(oracle_lib, f, b, cls, reg, iou)

@@ -1,7 +1,7 @@
 """CPU: the soft-NMS restatement (oracle/iouaware_oracle_softnms.c) against
   * tests/golden/soft_nms.npz, captured from the imported reference (nms_wrapper.soft_nms over the
     reference's own Cython module; get_bboxes with test_cfg.nms.type='soft_nms'),
-  * the reference module itself (oracle/_ref/soft_nms_cpu.so, built by oracle/build_ref.py from
+  * the reference module itself (oracle/_ref_local/soft_nms_cpu.so, built by oracle/build_ref.py from
     mmdet/ops/nms/src/soft_nms_cpu.pyx), on random and tie-heavy inputs: bit for bit.
 """
 import os
@@ -65,7 +65,7 @@ def test_soft_nms_matches_real_reference_module(oracle_lib):
     import build_ref
     ref = build_ref.load_soft()
     if ref is None:
-        pytest.skip('oracle/_ref/soft_nms_cpu.so not built (reference tree absent)')
+        pytest.skip('oracle/_ref_local/soft_nms_cpu.so not built (reference tree absent)')
     rs = np.random.RandomState(5)
     for trial in range(120):
         n = int(rs.randint(1, 400))
