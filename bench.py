@@ -69,6 +69,15 @@ HEAD_BYTES_PER_IMAGE = 68544000          # cls+reg+iou logits, fp32
 # written; the 3 225 600 B of box deltas are read by k_gather for the 4 693 candidates only
 ROWMAX_BYTES_PER_IMAGE = 64512000 + 806400 + 806400
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+BF16_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA peak (no 2:1 sparsity)
+# what "parity" means for the bf16 configuration (there is no 1e-4 contract in bf16: 8 mantissa bits)
+BF16_CONTRACT = ('bf16 storage, fp32 accumulation: post-conv path bit-exact against the oracle on the same '
+                 'bf16-rounded logits (tests/test_gpu_e2e.py::test_config3_bf16_batch16_post_conv_path); network: '
+                 'every stage output (C2..C5, P3..P7, 15 head outputs) no farther from the fp32 evaluation of the '
+                 'bf16-rounded weights than 1.5 x torch\'s own bf16 path + 1e-3 and below 0.6 x 2^-8 x sqrt(convs in '
+                 'front); detections: at least as many of the fp32 reference detections keep a twin (same class, IoU '
+                 '> 0.7) as with torch\'s own bf16 evaluation (86 vs 82 of 100 at 800x1344).  The 1e-4 / bit-exact-'
+                 'index contract of the north star is the fp32 path\'s')
 
 MODEL = dict(
     type='RetinaNet', pretrained=None,
@@ -752,6 +761,85 @@ def pipeline_record(model, device, batch, steps=5, warmup=2):
 STAGE_PREFIXES = ('ia::k_rowmax', 'ia::k_sel', 'ia::k_gather', 'ia::k_dec')
 
 
+@torch.no_grad()
+def conv3x3_bf16_rate(device, batch=16, reps=20):
+    """k_conv3x3_bf16 on the head-tower shape of config 3 (256 -> 256, 100 x 168, batch 16, bias +
+    ReLU): TFLOP/s from HIP events around `reps` back-to-back launches in this run."""
+    H, W, Cn = 100, 168, 256
+    x = torch.randn(batch, Cn, H, W, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cn, Cn, 3, 3, device=device) * 0.03).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cn, device=device)
+    wp = ops.conv3x3_bf16_pack(w)
+    for _ in range(3):
+        ops.conv3x3_bf16(x, wp, b, Cn, relu=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ops.conv3x3_bf16(x, wp, b, Cn, relu=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * batch * H * W * Cn * Cn * 9 / (ms * 1e-3) / 1e12
+    return {'kernel': 'k_conv3x3_bf16', 'shape': '256 -> 256, 100 x 168, batch %d, bias + ReLU' % batch,
+            'avg_launch_ms': round(ms, 4), 'achieved': round(tf, 1), 'peak': BF16_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(tf / BF16_PEAK_TFLOPS, 4),
+            'timing': 'HIP events around %d back-to-back launches in this run' % reps}
+
+
+OTHER_CONFIGS = (
+    # (record name, BASELINE config it stands for, backbone overrides, batch, dtype, steps, warmup)
+    ('config1_r50_fp32_batch1', 'config 1 on the GPU: IoU-aware RetinaNet R-50-FPN fp32, ONE 1333x800 image per step '
+     '(the reference CPU run of config 1 is cpu_baseline)', {}, 1, 'float32', 10, 3),
+    ('config3_r101_bf16_batch16', CONFIGS['r101-bf16'][0], dict(depth=101), 16, 'bfloat16', 5, 2),
+    ('config4_x101_64x4d_fp32_batch8', CONFIGS['x101-64x4d'][0],
+     dict(type='ResNeXt', depth=101, groups=64, base_width=4), 8, 'float32', 4, 2),
+)
+
+
+def other_configs_record(device, budget_s=60.0):
+    """BASELINE configs 1, 3, 4 as bounded sub-records of the default run: the
+    same whole inference path (network -> ops.get_bboxes) on one GPU, a few steps each between a
+    device synchronisation on both sides; config 3 also carries the bf16 3x3 kernel's rate."""
+    out, t_start = {}, time.time()
+    for name, what, backbone, batch, dtype_name, steps, warmup in OTHER_CONFIGS:
+        if time.time() - t_start > budget_s:
+            out[name] = {'skipped': 'time budget of %.0f s used up' % budget_s}
+            continue
+        try:
+            dtype = getattr(torch, dtype_name)
+            model = build_model(device, fuse=True, channels_last=True, winograd=True, backbone=backbone)
+            g = torch.Generator(device=device).manual_seed(4321)
+            imgs = torch.randn(batch, 3, PAD_H, PAD_W, device=device, generator=g)
+            if dtype != torch.float32:
+                model, imgs = model.to(dtype), imgs.to(dtype)
+            imgs = imgs.contiguous(memory_format=torch.channels_last)
+            st = Stepper(model, imgs, 1)
+            for _ in range(warmup):
+                st.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rec = {'workload': what + '; 3x800x1344, random-init weights, whole inference path incl. NMS',
+                   'batch': batch, 'dtype': 'fp32' if dtype == torch.float32 else 'bf16',
+                   'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3),
+                   'value': round(batch * steps / dt, 2), 'unit': 'img/s',
+                   'dets_per_image': int(st.last[2].float().mean().item())}
+            if dtype == torch.bfloat16:
+                rec['parity_contract'] = BF16_CONTRACT
+                rec['mfma'] = conv3x3_bf16_rate(device, batch)
+            out[name] = rec
+            del st, model, imgs
+            torch.cuda.empty_cache()
+        except Exception as exc:                            # the headline number must still print
+            out[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+    out['wall_s'] = round(time.time() - t_start, 1)
+    return out
+
+
 def stage_traffic():
     """HBM bytes per decode-stage pass (all of its kernels) from the committed PMC profile"""
     path = os.path.join(ROOT, 'profiles', PMC_PROFILE)
@@ -822,6 +910,8 @@ def main():
                     help='print the cpu_baseline record alone (no GPU needed)')
     ap.add_argument('--no-train', action='store_true', help='skip the training sub-record')
     ap.add_argument('--no-pipeline', action='store_true', help='skip the image -> result sub-record')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the BASELINE config 1 / 3 / 4 sub-records of the default run')
     ap.add_argument('--train-find', action='store_true',
                     help='MIOpen find mode for the training sub-record (adds ~8 minutes)')
     ap.add_argument('--miopen-find', action='store_true',
@@ -1030,8 +1120,10 @@ def main():
                 out['pipeline'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         else:
             out['pipeline'] = None
+        freed = False
         if world == 1 and headline and not args.no_train:
             del stepper, model, imgs
+            freed = True
             torch.cuda.empty_cache()
             try:
                 out['train'] = train_record(device, find=args.train_find)
@@ -1039,6 +1131,13 @@ def main():
                 out['train'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         else:
             out['train'] = None
+        if world == 1 and headline and not args.no_other_configs:
+            if not freed:
+                del stepper, model, imgs
+            torch.cuda.empty_cache()
+            out['other_configs'] = other_configs_record(device)
+        else:
+            out['other_configs'] = None
         print(json.dumps(out))
     if world > 1:
         dist.barrier(device_ids=[local_rank])

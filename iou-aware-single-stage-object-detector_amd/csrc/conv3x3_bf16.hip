@@ -25,6 +25,7 @@
 #include <tuple>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
+#include "ia_conv3.hpp"
 
 namespace ia {
 
@@ -46,20 +47,6 @@ constexpr int kCvMaxPatchPx128 = 256;     // (TH + 2) * (TW + 2) <= this: four 1
 constexpr int kCvMaxPatchPx64 = 128;      // ... two pieces per thread (8 x 8, 4 x 16)
 constexpr int kCvBigTiles = 2048;         // maps with this many 128-pixel tiles in the batch take (4, 1, 4)
 constexpr int kCvBN = 256;
-
-constexpr int kCvMaxGroups = 2;
-
-// One launch covers a list of feature maps (the pyramid levels of the shared-weight head) and up
-// to two groups (the cls / reg towers: different inputs, weights and outputs, one tile list).
-struct Conv3Args {
-    const uint16_t *x[kCvMaxGroups][IA_MAX_LEVELS];   // (B, H_l, W_l, .) bf16, pixel stride xs
-    uint16_t *y[kCvMaxGroups][IA_MAX_LEVELS];         // (B, H_l, W_l, .) bf16, pixel stride ys
-    const uint16_t *wp;                   // packed weights [groups][ntile][Cin / 32][9][256][32]
-    const float *bias;                    // (groups * Cout) or NULL
-    int32_t L, B, Cin, Cout, xs, ys, relu, ntile;     // Cin / Cout per group; ntile = ceil(Cout / 256)
-    int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], TH[IA_MAX_LEVELS], TW[IA_MAX_LEVELS];
-    int32_t tiles_y[IA_MAX_LEVELS], tiles_x[IA_MAX_LEVELS], tile_off[IA_MAX_LEVELS + 1];
-};
 
 __device__ __forceinline__ uint32_t bf16_rne(float f)
 {
@@ -323,10 +310,12 @@ static void conv3_tile_shape_search(int H, int W, int max_px, int max_rows, int 
 {
     double best = -1.0;
     TH = 4; TW = 16;
+    // patch pixels a workgroup's threads can stage (the ping-pong kernel's DMA pieces cover all its LDS rows)
+    const int max_patch = max_px == 256 ? max_rows : (max_px == 128 ? kCvMaxPatchPx128 : kCvMaxPatchPx64);
     for (int tw = 4; tw <= 64; ++tw) {
         for (int th = 2; th <= 64; ++th) {
             if (th * tw > max_px || (th + 2) * (tw + kCvPitchPad) > max_rows ||
-                (th + 2) * (tw + 2) > (max_px == 128 ? kCvMaxPatchPx128 : kCvMaxPatchPx64))
+                (th + 2) * (tw + 2) > max_patch)
                 continue;
             const int64_t ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
             const double eff = (double)H * W / ((double)ty * tx * max_px);      // useful rows per tile
@@ -391,10 +380,24 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     const bool narrow64 = (wnc == 1 && !f22) || (wnc == 2 && f12);
     hipStream_t st = (hipStream_t)stream;
     const int wnk = (wnc == 1 && !narrow64) ? 2 : wnc;         // "22" forced: 64 output channels on (2, 2, 2) as before
-    for (int pass = 0; pass < 2; ++pass) {            // pass 0: the large maps on (4, 1, 4); pass 1: the rest
+    // Cout > 128, maps with at least `pp_min` 256-pixel tiles in the launch (batch x groups x tiles): the
+    // eight-wavefront ping-pong kernel (conv3x3_bf16_pp.hip), one workgroup per CU -- a map must fill
+    // the chip's 256 CUs about once for it to pay.  IA_CONV3_PP=0 switches it off, IA_CONV3_PP=<n>
+    // sets the tile-count threshold (tools/time_conv3x3_bf16.py).
+    int pp_min = 256;
+    if (const char *e = getenv("IA_CONV3_PP")) pp_min = e[0] ? atoi(e) : 256;
+    if (pp_min <= 0 || wnc != 4 || forced) pp_min = 0x7fffffff;
+    bool is_pp[IA_MAX_LEVELS];
+    for (int l = 0; l < d->num_levels; ++l) {
+        int th, tw;
+        ia::conv3_tile_shape(d->H[l], d->W[l], ia::kPpTilePx, ia::kPpMaxRows, th, tw);
+        const int64_t n = (int64_t)d->batch * d->groups * ((d->H[l] + th - 1) / th) * ((d->W[l] + tw - 1) / tw);
+        is_pp[l] = n >= pp_min;
+    }
+    for (int pass = -1; pass < 2; ++pass) {           // pass -1: ping-pong maps; 0: the large maps on (4, 1, 4); 1: the rest
         const int mb = (pass == 0 && wnc == 4) ? 4 : (narrow64 ? 1 : 2);
-        const int px = 32 * mb * (4 / wnk);
-        const int rows = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
+        const int px = pass < 0 ? ia::kPpTilePx : 32 * mb * (4 / wnk);
+        const int rows = pass < 0 ? ia::kPpMaxRows : (px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64);
         ia::Conv3Args a;
         memset(&a, 0, sizeof(a));
         a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
@@ -407,7 +410,8 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
             ia::conv3_tile_shape(d->H[l], d->W[l], 128, ia::kCvMaxRows128, th, tw);
             const int64_t big_tiles = (int64_t)d->batch * ((d->H[l] + th - 1) / th) * ((d->W[l] + tw - 1) / tw);
             const bool big = wnc == 4 && (forced == 4 || (forced != 2 && big_tiles >= ia::kCvBigTiles));
-            if (big != (pass == 0)) continue;
+            if (is_pp[l] != (pass < 0)) continue;
+            if (pass >= 0 && big != (pass == 0)) continue;
             a.H[n] = d->H[l]; a.W[n] = d->W[l];
             for (int g = 0; g < d->groups; ++g) {
                 a.x[g][n] = static_cast<const uint16_t *>(d->x[g][l]);
@@ -424,6 +428,11 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         a.L = n;
         for (int l = n; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
+        if (pass < 0) {
+            const int rc = ia::launch_conv3x3_bf16_pp(a, grid, st);
+            if (rc) return rc;
+            continue;
+        }
         if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
         else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
         else if (mb == 1 && wnk == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 4, 1>), grid, dim3(256), 0, st, a);

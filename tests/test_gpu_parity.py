@@ -80,6 +80,7 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
         # channels are not: those heads are transposed to NCHW by ops.level_ptrs)
         in_place = (geom.Cin * dc[0].element_size()) % 16 == 0
         assert ops.geometry_for(geom, dc, dr, di).layout == (1 if in_place else 0)
+    natural = channels_last and (geom.Cin * dc[0].element_size()) % 16 == 0     # row-max array in p*A + a order
     shapes = [m['img_shape'] for m in metas]
     sfs = [m['scale_factor'] for m in metas]
     dets, labels, rows, num, dbg = ops.get_bboxes(geom, dc, dr, di, shapes, sfs, rescale,
@@ -106,7 +107,7 @@ def _check_layout(ops, oracle_lib, cls, reg, iou, geom, base, metas, rescale, sc
         for (h, w) in geom.featmap_sizes:
             n_l = h * w * geom.A
             dev = dbg['rowmax'][b][off:off + n_l]
-            if not channels_last:
+            if not natural:
                 dev = dev.reshape(geom.A, h * w).T.reshape(-1)
             assert G.same_bits(dev, o['rowmax'][off:off + n_l]), 'rowmax img %d' % b
             off += n_l

@@ -35,5 +35,9 @@ for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
         tv = bench(mine)
         var += '  %s: %.3f (%.0f)' % (v, tv, fl / tv / 1e9)
     del os.environ['IA_CONV3_VARIANT']
+    os.environ['IA_CONV3_PP'] = '1'             # the 256-pixel ping-pong kernel whatever the tile count
+    tv = bench(mine)
+    var += '  pp: %.3f (%.0f)' % (tv, fl / tv / 1e9)
+    del os.environ['IA_CONV3_PP']
     print('%3dx%3d  library conv + epilogue %.3f ms (%.0f TF)   own kernel %.3f ms (%.0f TF) |%s' % (H, W, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, var), flush=True)
 print('all levels: library %.3f ms, own %.3f ms' % tuple(tot))
