@@ -956,6 +956,9 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
     rccl_ranks, rank_devices = 1, None
+    # every rank on the cores of its GPU's NUMA node, a disjoint share each (no-op for one rank)
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    affinity = idist.pin_rank(local_rank, local_world, device_count=0 if args.dry_run else None)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='gloo' if args.dry_run else 'nccl')
@@ -980,7 +983,8 @@ def main():
                               'value': round(stepper.B * world * args.steps / elapsed, 3),
                               'unit': 'fake img/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks,
                               'backend': 'gloo', 'steps': args.steps, 'warmup': args.warmup,
-                              'exchange_ok': ok, 'launched_by': launched_by}))
+                              'exchange_ok': ok, 'launched_by': launched_by,
+                              'affinity_rank0': affinity}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -1045,7 +1049,7 @@ def main():
                       'images/sec at 1333x800, IoU-aware RetinaNet (%s)' % args.config,
             'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': world,
             'rccl_ranks': rccl_ranks, 'rank_devices': rank_devices,
-            'launched_by': launched_by,
+            'launched_by': launched_by, 'affinity_rank0': affinity,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['capi.hip', 'decode.hip', 'select.hip', 'nms.hip', 'loss.hip', 'elementwise.hip', 'assign.hip',
            'softnms.hip', 'preproc.hip', 'wino.hip', 'gemm.hip', 'lazynms.hip', 'headloss.hip', 'gconv.hip',
-           'trainops.hip', 'bignms.hip', 'conv3x3_bf16.hip', 'conv3x3_bf16_pp.hip', 'conv1x1_stream.hip', 'im2col.hip', 'nms64.hip', 'stem.hip']
+           'trainops.hip', 'bignms.hip', 'conv3x3_bf16.hip', 'conv1x1_stream.hip', 'im2col.hip', 'nms64.hip', 'stem.hip']
 HEADERS = ['ia_math.hpp', 'ia_block.hpp', 'ia_internal.hpp', 'ia_loss.hpp', 'ia_rowmax_dev.hpp', 'ia_gather_dev.hpp', 'ia_nms.hpp', 'ia_conv3.hpp', '../../include/iouaware.h']
 OUT = os.path.join(HERE, 'libiouaware_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',

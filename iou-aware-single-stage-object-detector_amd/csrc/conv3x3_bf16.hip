@@ -62,7 +62,18 @@ __device__ __forceinline__ uint32_t bf16_rne(float f)
 // i.e. two or three workgroups, and one's prologue / epilogue overlaps the others' K loops (the
 // 8-wavefront workgroup of round 3, alone on its CU, ran 12-40 % slower).  WN = 4 for Cout > 128;
 // the narrow backbone layers turn column wavefronts into row wavefronts (WN = 2 / 1).
-template <int MB, int WM, int WN>
+// PIPE = 2 (the (4, 1, 4) variant): the A fragments software-pipelined through a ring of four registers
+// -- the fragment of MFMA pair p + 3 is requested in front of pair p (a step = 8 pairs of MFMAs on one
+// A fragment; pairs 8..10 = the next step's first three), so no LDS latency stands in front of any
+// MFMA: `s_waitcnt lgkmcnt(3)` instead of the old `ds_read x2; lgkmcnt(1); v_mfma` at the head of
+// every step.  Needs the next chunk's patch one step early (barrier behind tap 7) and a second
+// barrier per chunk (behind tap 2) between the last reads of a patch buffer and the stores that
+// overwrite it.  16 registers for the ring (the half-step form -- the kk = 1 fragments under the kk = 0
+// MFMAs, the next step's kk = 0 fragments under the kk = 1 MFMAs, 32 registers -- spilled at the 256
+// the two-wavefront-per-SIMD budget allows and lost: 0.322 against 0.312 ms).  Round 5, 100 x 168 at
+// batch 16: 0.312 -> 0.300 ms; counters: matrix pipe 0.53 -> 0.59 busy, and the chip answers with 1.67
+// instead of 1.80 GHz (profiles/r05_conv3x3_bf16_pmc.txt): busy x clock, i.e. throughput, +2.4 %.
+template <int MB, int WM, int WN, int PIPE = 0>
 __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(Conv3Args a)
 {
     constexpr int kThreads = 64 * WM * WN;
@@ -169,6 +180,13 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
     CV_LOAD_B(nsteps > 1 ? 1 : 0, by0, by1, by2, by3)
     CV_STORE_A(0)
     __syncthreads();
+    bf16x8 fr0, fr1, fr2, fr3;                // PIPE: ring of four fragments, read three MFMA pairs ahead
+    if constexpr (PIPE == 2) {
+        static_assert(PIPE != 2 || MB == 4, "the fragment ring is laid out for four pixel blocks");
+        fr0 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[0]);
+        fr1 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[1 % MB]);
+        fr2 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[2 % MB]);
+    }
 
     // One step: the MFMAs of (chunk, TAP): A from the patch (a tap only shifts the read window), B
     // from the register set X; set Z receives the fragments of step + 2.  No barrier inside a
@@ -186,6 +204,14 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
             acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], f1, acc[i][1], 0, 0, 0);     \
         }                                                                                           \
     }
+#define CV_PAIR(DST, SRC, USE, I, G0, G1)                                                          \
+    {                                                                                               \
+        DST = *reinterpret_cast<const bf16x8 *>(SRC);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(USE, G0, acc[I][0], 0, 0, 0);           \
+        acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(USE, G1, acc[I][1], 0, 0, 0);           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
 #define CV_STEP(TAP, X0, X1, X2, X3, Z0, Z1, Z2, Z3)                                                \
     {                                                                                               \
         constexpr int dy = (TAP) / 3, dx = (TAP) - dy * 3;                                          \
@@ -202,9 +228,29 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
            variant: 0.321-0.335 against 0.307-0.319 ms */                                          \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         const unsigned char *ab = s_a[0] + cur * (kPatch * kCvRow) + (dy * PWl + dx) * kCvRow;      \
-        CV_MFMA(0, X0, X2)                                                                          \
-        CV_MFMA(1, X1, X3)                                                                          \
+        if constexpr (PIPE == 2) {                                                                  \
+            constexpr int ndy = ((TAP) + 1) % 9 / 3, ndx = ((TAP) + 1) % 9 - ndy * 3;               \
+            const unsigned char *abn = s_a[0] + ((TAP) == 8 ? (cur ^ 1) : cur) * (kPatch * kCvRow) + (ndy * PWl + ndx) * kCvRow; \
+            const bf16x8 g00 = __builtin_bit_cast(bf16x8, X0), g10 = __builtin_bit_cast(bf16x8, X2); \
+            const bf16x8 g01 = __builtin_bit_cast(bf16x8, X1), g11 = __builtin_bit_cast(bf16x8, X3); \
+            /* pair p = (kk, block i) uses ring slot p & 3; in front of it the fragment of pair p + 3 \
+               is requested (pairs 8, 9, 10 = the next step's first three) */                       \
+            CV_PAIR(fr3, ab + a_off[3 % MB], fr0, 0, g00, g10)                                      \
+            CV_PAIR(fr0, ab + a_off[0] + 32, fr1, 1 % MB, g00, g10)                                 \
+            CV_PAIR(fr1, ab + a_off[1 % MB] + 32, fr2, 2 % MB, g00, g10)                            \
+            CV_PAIR(fr2, ab + a_off[2 % MB] + 32, fr3, 3 % MB, g00, g10)                            \
+            CV_PAIR(fr3, ab + a_off[3 % MB] + 32, fr0, 0, g01, g11)                                 \
+            CV_PAIR(fr0, abn + a_off[0], fr1, 1 % MB, g01, g11)                                     \
+            CV_PAIR(fr1, abn + a_off[1 % MB], fr2, 2 % MB, g01, g11)                                \
+            CV_PAIR(fr2, abn + a_off[2 % MB], fr3, 3 % MB, g01, g11)                                \
+        } else {                                                                                    \
+            CV_MFMA(0, X0, X2)                                                                      \
+            CV_MFMA(1, X1, X3)                                                                      \
+        }                                                                                           \
         if ((TAP) == 6) CV_STORE_A(cur ^ 1)                                                         \
+        /* PIPE: (tap 7) the next patch is complete before tap 8 prefetches from it; (tap 2) nobody \
+           reads the other buffer's old content any more before tap 6 overwrites it */              \
+        if (PIPE && ((TAP) == 7 || (TAP) == 2)) __syncthreads();                                    \
     }
     int cur = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -219,10 +265,11 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
         CV_STEP(7, by0, by1, by2, by3, bx0, bx1, bx2, bx3)
         CV_STEP(8, bz0, bz1, bz2, bz3, by0, by1, by2, by3)
         // nine steps = three rotations of the sets: the names are back where they started
-        __syncthreads();          // every wavefront is done with patch `cur`, the next one is stored
+        if (!PIPE) __syncthreads();   // every wavefront is done with patch `cur`, the next one is stored
         cur ^= 1;
     }
 #undef CV_STEP
+#undef CV_PAIR
 #undef CV_MFMA
 #undef CV_LOAD_A
 #undef CV_STORE_A
@@ -310,8 +357,7 @@ static void conv3_tile_shape_search(int H, int W, int max_px, int max_rows, int 
 {
     double best = -1.0;
     TH = 4; TW = 16;
-    // patch pixels a workgroup's threads can stage (the ping-pong kernel's DMA pieces cover all its LDS rows)
-    const int max_patch = max_px == 256 ? max_rows : (max_px == 128 ? kCvMaxPatchPx128 : kCvMaxPatchPx64);
+    const int max_patch = max_px == 128 ? kCvMaxPatchPx128 : kCvMaxPatchPx64;     // patch pixels a workgroup's threads can stage
     for (int tw = 4; tw <= 64; ++tw) {
         for (int th = 2; th <= 64; ++th) {
             if (th * tw > max_px || (th + 2) * (tw + kCvPitchPad) > max_rows ||
@@ -380,24 +426,10 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
     const bool narrow64 = (wnc == 1 && !f22) || (wnc == 2 && f12);
     hipStream_t st = (hipStream_t)stream;
     const int wnk = (wnc == 1 && !narrow64) ? 2 : wnc;         // "22" forced: 64 output channels on (2, 2, 2) as before
-    // Cout > 128, maps with at least `pp_min` 256-pixel tiles in the launch (batch x groups x tiles): the
-    // eight-wavefront ping-pong kernel (conv3x3_bf16_pp.hip), one workgroup per CU -- a map must fill
-    // the chip's 256 CUs about once for it to pay.  IA_CONV3_PP=0 switches it off, IA_CONV3_PP=<n>
-    // sets the tile-count threshold (tools/time_conv3x3_bf16.py).
-    int pp_min = 256;
-    if (const char *e = getenv("IA_CONV3_PP")) pp_min = e[0] ? atoi(e) : 256;
-    if (pp_min <= 0 || wnc != 4 || forced) pp_min = 0x7fffffff;
-    bool is_pp[IA_MAX_LEVELS];
-    for (int l = 0; l < d->num_levels; ++l) {
-        int th, tw;
-        ia::conv3_tile_shape(d->H[l], d->W[l], ia::kPpTilePx, ia::kPpMaxRows, th, tw);
-        const int64_t n = (int64_t)d->batch * d->groups * ((d->H[l] + th - 1) / th) * ((d->W[l] + tw - 1) / tw);
-        is_pp[l] = n >= pp_min;
-    }
-    for (int pass = -1; pass < 2; ++pass) {           // pass -1: ping-pong maps; 0: the large maps on (4, 1, 4); 1: the rest
+    for (int pass = 0; pass < 2; ++pass) {            // pass 0: the large maps on (4, 1, 4); pass 1: the rest
         const int mb = (pass == 0 && wnc == 4) ? 4 : (narrow64 ? 1 : 2);
-        const int px = pass < 0 ? ia::kPpTilePx : 32 * mb * (4 / wnk);
-        const int rows = pass < 0 ? ia::kPpMaxRows : (px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64);
+        const int px = 32 * mb * (4 / wnk);
+        const int rows = px == 128 ? ia::kCvMaxRows128 : ia::kCvMaxRows64;
         ia::Conv3Args a;
         memset(&a, 0, sizeof(a));
         a.wp = static_cast<const uint16_t *>(wp); a.bias = bias;
@@ -410,8 +442,7 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
             ia::conv3_tile_shape(d->H[l], d->W[l], 128, ia::kCvMaxRows128, th, tw);
             const int64_t big_tiles = (int64_t)d->batch * ((d->H[l] + th - 1) / th) * ((d->W[l] + tw - 1) / tw);
             const bool big = wnc == 4 && (forced == 4 || (forced != 2 && big_tiles >= ia::kCvBigTiles));
-            if (is_pp[l] != (pass < 0)) continue;
-            if (pass >= 0 && big != (pass == 0)) continue;
+            if (big != (pass == 0)) continue;
             a.H[n] = d->H[l]; a.W[n] = d->W[l];
             for (int g = 0; g < d->groups; ++g) {
                 a.x[g][n] = static_cast<const uint16_t *>(d->x[g][l]);
@@ -428,12 +459,10 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         a.L = n;
         for (int l = n; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
-        if (pass < 0) {
-            const int rc = ia::launch_conv3x3_bf16_pp(a, grid, st);
-            if (rc) return rc;
-            continue;
-        }
-        if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
+        // IA_CONV3_PIPE=0: the (4, 1, 4) variant without the fragment ring (A/B runs)
+        static const int pipe = [] { const char *e = getenv("IA_CONV3_PIPE"); return e ? atoi(e) : 2; }();
+        if (wnc == 4 && mb == 4 && pipe == 2) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4, 2>), grid, dim3(256), 0, st, a);
+        else if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
         else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
         else if (mb == 1 && wnk == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 4, 1>), grid, dim3(256), 0, st, a);
         else if (mb == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 2, 2>), grid, dim3(256), 0, st, a);

@@ -1,5 +1,5 @@
-// Argument block shared by the bf16 3x3 convolution kernels (conv3x3_bf16.hip: the four-wavefront
-// variants; conv3x3_bf16_pp.hip: the 256-pixel ping-pong variant for large maps).
+// Argument block of the bf16 3x3 convolution kernels (conv3x3_bf16.hip; the archived 256-pixel
+// ping-pong experiment, tools/experiments/conv3x3_bf16_pingpong_256px.hip.txt, takes the same block).
 #pragma once
 #include "ia_internal.hpp"
 
@@ -18,10 +18,5 @@ struct Conv3Args {
     int32_t H[IA_MAX_LEVELS], W[IA_MAX_LEVELS], TH[IA_MAX_LEVELS], TW[IA_MAX_LEVELS];
     int32_t tiles_y[IA_MAX_LEVELS], tiles_x[IA_MAX_LEVELS], tile_off[IA_MAX_LEVELS + 1];
 };
-
-// ping-pong variant: 256-pixel tiles, LDS rows (TH + 2) * (TW + 16) of one halo patch buffer
-constexpr int kPpMaxRows = 576;
-constexpr int kPpTilePx = 256;
-int launch_conv3x3_bf16_pp(const Conv3Args &a, dim3 grid, hipStream_t st);
 
 }  // namespace ia

@@ -30,6 +30,113 @@ def init_dist(launcher='pytorch', backend='nccl', **kwargs):
     return rank, dist.get_world_size()
 
 
+# ------------------------------------------------------------------ rank -> cores of the GPU's NUMA node
+def _parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(','):
+        if '-' in part:
+            lo, hi = part.split('-')
+            out += list(range(int(lo), int(hi) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def gpu_numa_node(pci_bus_id, sysfs='/sys'):
+    """NUMA node the GPU with this PCI address ('0000:c1:00.0') hangs off, or -1"""
+    if not pci_bus_id:
+        return -1
+    txt = _read(os.path.join(sysfs, 'bus/pci/devices', pci_bus_id.lower(), 'numa_node'))
+    try:
+        return int(txt)
+    except (TypeError, ValueError):
+        return -1
+
+
+def _physical_cores(cpus, sysfs='/sys'):
+    """one hardware thread per physical core, ascending"""
+    seen, out = set(), []
+    for c in sorted(cpus):
+        sib = _read(os.path.join(sysfs, 'devices/system/cpu/cpu%d/topology/thread_siblings_list' % c))
+        key = tuple(sorted(_parse_cpulist(sib))) if sib else (c,)
+        if key not in seen:
+            seen.add(key)
+            out.append(c)
+    return out
+
+
+def rank_cpu_plan(local_rank, local_world, numa_nodes, allowed, sysfs='/sys'):
+    """The cores rank `local_rank` of `local_world` ranks on this node should run on.
+    numa_nodes[r] = NUMA node of rank r's GPU (-1: unknown).  Ranks whose GPUs share a NUMA node
+    split that node's physical cores (restricted to `allowed`, the launcher's affinity mask) into
+    equal contiguous shares; a rank with an unknown node takes the same share of ALL allowed
+    cores.  -> (sorted cpu ids incl. the SMT siblings of the chosen cores, description)"""
+    allowed = set(allowed)
+    node = numa_nodes[local_rank] if 0 <= local_rank < len(numa_nodes) else -1
+    cpus = None
+    if node >= 0:
+        txt = _read(os.path.join(sysfs, 'devices/system/node/node%d/cpulist' % node))
+        if txt:
+            cpus = [c for c in _parse_cpulist(txt) if c in allowed]
+    if cpus:
+        peers = [r for r in range(local_world) if r < len(numa_nodes) and numa_nodes[r] == node]
+        how = 'NUMA node %d' % node
+    else:
+        cpus, peers, how = sorted(allowed), list(range(local_world)), 'all allowed cores (GPU NUMA node unknown)'
+    cores = _physical_cores(cpus, sysfs)
+    share = max(1, len(cores) // max(1, len(peers)))
+    k = peers.index(local_rank) if local_rank in peers else 0
+    mine = cores[k * share:(k + 1) * share] or cores[-share:]
+    out = set()
+    for c in mine:
+        sib = _read(os.path.join(sysfs, 'devices/system/cpu/cpu%d/topology/thread_siblings_list' % c))
+        out.update(x for x in (_parse_cpulist(sib) if sib else [c]) if x in allowed)
+    return sorted(out), '%d of %d physical cores of %s (share %d of %d)' % (len(mine), len(cores), how,
+                                                                       k + 1, len(peers))
+
+
+def pin_rank(local_rank, local_world, device_count=None, sysfs='/sys', apply=True):
+    """Bind this process (and the threads it starts later) to the cores of the NUMA node its GPU
+    hangs off, a disjoint share per rank, and size the host thread pools to it.  One Python feeder per
+    GPU issues ~140 launches per 20 ms step; eight unpinned feeders on a two-socket host migrate
+    between sockets and share cores with each other's helper threads.  The
+    reference leaves placement to the launcher (tools/dist_test.sh:9-10).  -> record for the
+    benchmark line; never raises (an unreadable topology leaves the affinity alone)."""
+    rec = {'local_rank': int(local_rank), 'pinned': False}
+    try:
+        allowed = os.sched_getaffinity(0)
+        nodes = []
+        n = device_count if device_count is not None else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+        for r in range(local_world):
+            bus = None
+            if r < n:
+                pr = torch.cuda.get_device_properties(r)
+                if hasattr(pr, 'pci_bus_id'):
+                    bus = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id,
+                                                getattr(pr, 'pci_device_id', 0))
+            nodes.append(gpu_numa_node(bus, sysfs))
+        cpus, how = rank_cpu_plan(local_rank, local_world, nodes, allowed, sysfs)
+        rec.update(numa_node=nodes[local_rank] if local_rank < len(nodes) else -1, cpus=len(cpus),
+                   first_cpu=cpus[0] if cpus else None, plan=how)
+        if apply and cpus and local_world > 1:
+            os.sched_setaffinity(0, cpus)
+            threads = max(1, min(8, len(cpus) // 2 or 1))
+            os.environ['OMP_NUM_THREADS'] = str(threads)
+            torch.set_num_threads(threads)
+            rec.update(pinned=True, host_threads=threads)
+    except Exception as exc:                                 # topology files differ between hosts
+        rec['error'] = '%s: %s' % (type(exc).__name__, exc)
+    return rec
+
+
 def get_dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

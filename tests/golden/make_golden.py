@@ -862,6 +862,17 @@ def gen_focal_op():
         tag = 'g%g_a%g' % (gamma, alpha)
         out['loss_' + tag] = loss.detach().numpy()
         out['grad_' + tag] = tx.grad.numpy()
+        # the same function evaluated in the OTHER storage types of the reference op's dispatch
+        # (sigmoid_focal_loss_cuda.cu:115,151 AT_DISPATCH_FLOATING_TYPES_AND_HALF: intermediates in
+        # scalar_t): double, and half on the half-rounded logits -- ADVICE r4: the dtype-generic HIP op
+        # computes in fp32 and rounds once; these pin how far that is from scalar_t arithmetic
+        for name, dt in (('64', torch.float64), ('16', torch.float16)):
+            td = torch.from_numpy(x).to(dt).clone().requires_grad_(True)
+            ld = ref_losses.py_sigmoid_focal_loss(td, onehot.to(dt), torch.ones(N, C, dtype=dt), gamma=gamma,
+                                                  alpha=alpha, reduction='none')
+            (ld * torch.from_numpy(up).to(dt)).sum().backward()
+            out['loss%s_%s' % (name, tag)] = ld.detach().numpy()
+            out['grad%s_%s' % (name, tag)] = td.grad.numpy()
     out['params'] = np.array([[2.0, 0.25], [1.5, 0.4], [0.0, 0.5]], np.float32)
     save('focal_op', **out)
 

@@ -2,10 +2,13 @@
 the images rank, rank+W, ... (DistributedSampler order); one all_gather of
 fixed-size records returns all detections in dataset order on every rank."""
 import os
+import json
 import socket
+import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -313,3 +316,68 @@ def test_train_step_none_loss_raises_instead_of_hanging_the_collective():
     net = NoLoss()
     assert train_step(net, torch.optim.SGD(net.parameters(), lr=0.1), torch.zeros(1, 3, 8, 8),
                       [{}], [None], [None]) is None
+
+
+def _fake_topology(root, nodes=2, cores_per_node=8, gpus=8):
+    """a sysfs tree: `nodes` NUMA nodes of `cores_per_node` physical cores with two hardware
+    threads each (cpu c and c + nodes * cores_per_node), GPU g on node g // (gpus / nodes)"""
+    ncore = nodes * cores_per_node
+    for n in range(nodes):
+        d = os.path.join(root, 'devices/system/node/node%d' % n)
+        os.makedirs(d)
+        lo = n * cores_per_node
+        with open(os.path.join(d, 'cpulist'), 'w') as f:
+            f.write('%d-%d,%d-%d\n' % (lo, lo + cores_per_node - 1, ncore + lo, ncore + lo + cores_per_node - 1))
+    for c in range(2 * ncore):
+        d = os.path.join(root, 'devices/system/cpu/cpu%d/topology' % c)
+        os.makedirs(d)
+        with open(os.path.join(d, 'thread_siblings_list'), 'w') as f:
+            f.write('%d,%d\n' % (c % ncore, c % ncore + ncore))
+    bus = []
+    for g in range(gpus):
+        name = '0000:%02x:00.0' % (0x10 + g)
+        d = os.path.join(root, 'bus/pci/devices', name)
+        os.makedirs(d)
+        with open(os.path.join(d, 'numa_node'), 'w') as f:
+            f.write('%d\n' % (g // (gpus // nodes)))
+        bus.append(name)
+    return bus
+
+
+def test_rank_cpu_plan_splits_the_numa_node_of_each_gpu(tmp_path):
+    """eight ranks on a two-socket host -- every rank on the cores of ITS GPU's
+    NUMA node, the four ranks of a node on disjoint shares, SMT siblings kept together"""
+    from iouaware import dist as idist
+    root = str(tmp_path)
+    bus = _fake_topology(root)
+    nodes = [idist.gpu_numa_node(b, root) for b in bus]
+    assert nodes == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert idist.gpu_numa_node('0000:ff:00.0', root) == -1 and idist.gpu_numa_node(None, root) == -1
+    allowed = set(range(32))
+    plans = [idist.rank_cpu_plan(r, 8, nodes, allowed, root)[0] for r in range(8)]
+    assert plans[0] == [0, 1, 16, 17] and plans[3] == [6, 7, 22, 23]
+    assert plans[4] == [8, 9, 24, 25] and plans[7] == [14, 15, 30, 31]
+    flat = [c for p in plans for c in p]
+    assert len(flat) == len(set(flat)) == 32                      # disjoint, everything used
+    # a launcher that restricted the affinity mask: shares come out of the allowed cores only
+    cpus, how = idist.rank_cpu_plan(1, 2, [0, 0], {0, 1, 2, 3, 16, 17, 18, 19}, root)
+    assert cpus == [2, 3, 18, 19] and 'NUMA node 0' in how
+    # unknown NUMA node (-1, e.g. a VM): an equal share of all allowed cores
+    cpus, how = idist.rank_cpu_plan(1, 2, [-1, -1], allowed, root)
+    assert cpus == list(range(8, 16)) + list(range(24, 32)) and 'unknown' in how
+    # pin_rank never raises and leaves a single rank alone
+    rec = idist.pin_rank(0, 1, device_count=0, sysfs=root)
+    assert rec['pinned'] is False and 'error' not in rec
+
+
+def test_bench_dry_run_ranks_are_pinned_to_disjoint_cores():
+    """two gloo ranks of `bench.py --dry-run`: rank 0 reports its share of the host's cores"""
+    if len(os.sched_getaffinity(0)) < 4:
+        pytest.skip('needs at least four cores')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run',
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    aff = rec['affinity_rank0']
+    assert aff['pinned'] is True and aff['cpus'] >= 1 and 'share 1 of 2' in aff['plan'], aff
+    assert aff['cpus'] <= len(os.sched_getaffinity(0)) // 2 + 1

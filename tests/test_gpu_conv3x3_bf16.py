@@ -7,18 +7,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['default', 'pp', 'no-pp'])
-def variant(request, monkeypatch):
-    """kernel selection of ia_conv3x3_bf16_levels for Cout > 128: 'default' (maps with at least 256
-    256-pixel tiles in the launch take the eight-wavefront ping-pong kernel, conv3x3_bf16_pp.hip),
-    'pp' (every map does: IA_CONV3_PP=1), 'no-pp' (none does: IA_CONV3_PP=0)"""
-    if request.param == 'pp':
-        monkeypatch.setenv('IA_CONV3_PP', '1')
-    elif request.param == 'no-pp':
-        monkeypatch.setenv('IA_CONV3_PP', '0')
-    return request.param
-
-
 @pytest.mark.parametrize('B,H,W,ci,co,relu,bias', [
     (1, 7, 11, 32, 256, False, False),        # one partial tile
     (2, 13, 21, 64, 256, True, True),
@@ -31,10 +19,10 @@ def variant(request, monkeypatch):
     (2, 37, 53, 128, 128, True, True),        # ResNet stage 2: (2, 2, 2), 128-pixel tiles with overhang
     (1, 25, 42, 512, 512, True, True),        # ResNet stage 4
     (1, 20, 30, 64, 96, False, True),         # 64 < Cout <= 128, partial second column
-    (16, 100, 168, 256, 256, True, True),     # config 3's head tower on P3: 1 120 ping-pong tiles (default route)
+    (16, 100, 168, 256, 256, True, True),     # config 3's head tower on P3 at its batch: the (4, 1, 4) variant with the fragment ring
     (3, 61, 47, 160, 320, True, True),        # odd sizes, five chunks, a partial second column tile
 ])
-def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias, variant):
+def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias):
     from iouaware import ops
     g = torch.Generator(device='cuda').manual_seed(H * W + ci)
     x = torch.randn(B, ci, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -59,7 +47,7 @@ def test_conv3x3_bf16_matches_fp64_convolution(B, H, W, ci, co, relu, bias, vari
     assert e_mine <= 1.2 * e_eager + 1e-6, (e_mine, e_eager)
 
 
-def test_conv3x3_bf16_levels_groups_slices_and_odd_widths(variant):
+def test_conv3x3_bf16_levels_groups_slices_and_odd_widths():
     """one launch over five pyramid levels and two groups whose tensors are channel halves of
     512-channel activations (the cls / reg towers), and a 720-channel output (three column tiles,
     the last one partial) -- against fp64 convolutions of the bf16-rounded inputs"""

@@ -17,7 +17,10 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n
 tot = [0.0, 0.0]
 for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
-    x = torch.randn(B, 256, H, W, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, 256, H, W, device='cuda')
+    kind = os.environ.get('IA_BENCH_INPUT', 'randn')        # randn | relu (what a tower layer really reads) | zeros
+    x = x.clamp(min=0) if kind == 'relu' else (x * 0 if kind == 'zeros' else x)
+    x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(256, 256, 3, 3, device='cuda') * 0.03).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     b = torch.randn(256, device='cuda')
     wp = ops.conv3x3_bf16_pack(w)
@@ -35,9 +38,5 @@ for (H, W) in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]:
         tv = bench(mine)
         var += '  %s: %.3f (%.0f)' % (v, tv, fl / tv / 1e9)
     del os.environ['IA_CONV3_VARIANT']
-    os.environ['IA_CONV3_PP'] = '1'             # the 256-pixel ping-pong kernel whatever the tile count
-    tv = bench(mine)
-    var += '  pp: %.3f (%.0f)' % (tv, fl / tv / 1e9)
-    del os.environ['IA_CONV3_PP']
     print('%3dx%3d  library conv + epilogue %.3f ms (%.0f TF)   own kernel %.3f ms (%.0f TF) |%s' % (H, W, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, var), flush=True)
 print('all levels: library %.3f ms, own %.3f ms' % tuple(tot))
