@@ -130,6 +130,7 @@ class Stepper(object):
     INSIDE the steps of the timed region (two event records per step, no synchronisation); the
     back-to-back figures of decode_stage_roofline() stay beside it."""
     events, ev_next = (), 0                  # (class defaults: subclasses with their own __init__)
+    pending = results = None
 
     def __init__(self, model, imgs, world):
         self.model, self.imgs, self.world = model, imgs, world
@@ -137,6 +138,28 @@ class Stepper(object):
         self.cfg = model.test_cfg
         self.last = None
         self.events, self.ev_next = [], 0
+        # the step ends where the reference's simple_test ends (single_stage.py:90-96): the rank's
+        # detections on the host as per-class arrays (bbox2result).  Batch i's device-to-host copy
+        # (one pinned record, ~19 KB) is enqueued behind its detections and COLLECTED while batch
+        # i + 1 runs on the device; drain() collects the last one inside the timed region.
+        self.pending, self.results, self.host_buf, self.flip = None, None, [None, None], 0
+
+    def submit_results(self, dets, labels, num):
+        from iouaware.detectors import PendingResults
+        rec = idist.pack_detections(dets, labels, num)
+        buf = self.host_buf[self.flip]
+        if buf is None or buf.shape != rec.shape:
+            buf = self.host_buf[self.flip] = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+        self.flip ^= 1
+        buf.copy_(rec, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return PendingResults(buf, done, dets.shape[1], self.model.bbox_head.num_classes)
+
+    def drain(self):
+        """collect what is still on its way (end of the warm-up and of the timed region)"""
+        if self.pending is not None:
+            self.results, self.pending = self.pending.collect(), None
 
     def stage_events(self, n, skip=0):
         """arm n event pairs for the steps after the next `skip` ones (created by one record each:
@@ -165,8 +188,12 @@ class Stepper(object):
                 ops.stage_events(None, None)
             self.ev_next += 1
         dets, labels, num, cls, reg, iou = self.local_detections(timed)
+        nxt = self.submit_results(dets, labels, num) if dets.is_cuda else None
         if self.world > 1:
             dets, labels, num = idist.all_gather_detections(dets, labels, num)
+        if self.pending is not None:
+            self.results = self.pending.collect()          # the previous batch: host work under this batch's device work
+        self.pending = nxt
         self.last = (dets, labels, num, cls, reg, iou)
         return dets
 
@@ -519,17 +546,24 @@ def wino_roofline(stepper, steps=2):
                      % steps)
 
 
-def timed_region(step, steps, warmup, world, sync, barrier, device):
+def timed_region(step, steps, warmup, world, sync, barrier, device, drain=None):
     """the driver's timing contract: W untimed warm-up steps, then EXACTLY K steps between
-    barrier + device synchronisation on both sides; the MAX over ranks of the elapsed time."""
+    barrier + device synchronisation on both sides; the MAX over ranks of the elapsed time.
+    drain: finishes whatever the last step left in flight on the host side (the last batch's
+    result collection) -- called before the clock starts and before it stops, so the K steps'
+    results are complete inside the timed region."""
     for _ in range(warmup):
         step()
+    if drain is not None:
+        drain()
     if world > 1:
         barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if drain is not None:
+        drain()
     if world > 1:
         barrier()
     sync()
@@ -817,10 +851,12 @@ def other_configs_record(device, budget_s=60.0):
             st = Stepper(model, imgs, 1)
             for _ in range(warmup):
                 st.step()
+            st.drain()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 st.step()
+            st.drain()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             rec = {'workload': what + '; 3x800x1344, random-init weights, whole inference path incl. NMS',
@@ -1026,8 +1062,9 @@ def main():
 
     if rank == 0:
         stepper.stage_events(args.steps, skip=args.warmup)
-    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device)
+    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device, drain=stepper.drain)
     in_step = stepper.stage_times_ms() if rank == 0 else []
+    host_results = stepper.results
 
     wino = wino_roofline(stepper) if rank == 0 and dtype == torch.float32 else None
     if rank == 0:
@@ -1058,9 +1095,15 @@ def main():
                                  'miopen': 'find mode' if args.miopen_find else 'immediate mode (stem only)'},
             'config': {'workload': ('IoU-aware RetinaNet R-50-FPN fp32, batch 8 per GPU, '
                                     '3x800x1344 (1333x800 padded to /32), random-init weights, '
-                                    'whole inference path incl. NMS') if headline else
+                                    'whole inference path incl. NMS, device-to-host copy and bbox2result '
+                                    '(the reference\'s simple_test: per-class arrays on the host; batch i\'s '
+                                    'host part runs under batch i+1\'s device part, the last one inside '
+                                    'the timed region)') if headline else
                                    ('BASELINE %s; 3x800x1344, random-init weights, whole '
-                                    'inference path incl. NMS' % cfg_name),
+                                    'inference path incl. NMS, D2H and bbox2result' % cfg_name),
+                       'host_results': {'images': len(host_results) if host_results else 0,
+                                        'classes_per_image': len(host_results[0]) if host_results else 0,
+                                        'dets_image0': int(sum(r.shape[0] for r in host_results[0])) if host_results else 0},
                        'global_batch': batch * world, 'parallelism': 'dp%d' % world,
                        'dets_per_image': int(stepper.last[2].float().mean().item())},
             # SURVEY 8(d)'s unit: the decode stage (row-max + top-k + gather), cls + reg + iou

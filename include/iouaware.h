@@ -182,12 +182,6 @@ int ia_multiclass_soft_nms(const float *boxes, const float *scores_t, int batch,
 size_t ia_get_bboxes_workspace_bytes(const ia_head_geom *g, int batch);
 size_t ia_get_bboxes_status_offset(const ia_head_geom *g, int batch);
 int ia_debug_fused_spin_limit(int64_t limit);
-/* The decode stage of ia_get_bboxes* / ia_decode_stage on TWO streams (channels-last heads on the
- * fused route, at least two levels): the first (largest) level on the caller's stream, the others on a
- * library-owned high-priority stream, forked and joined by events inside the call -- to the caller
- * the stage is still "everything in order on `stream`".  1: on (the default; IA_DECODE_SPLIT=0 in the
- * environment switches it off), 0: one stream, -1: back to the environment's choice.  Tests / A-B runs. */
-int ia_debug_decode_split(int mode);
 /* Profiling hook (bench.py): two caller-owned hipEvent_t (as void *) that every later
  * ia_get_bboxes / ia_get_bboxes_lazy / ia_decode_stage call records on ITS stream -- `begin` in
  * front of the decode stage's first launch (row-max), `end` behind its last one (gather / decode) --

@@ -3,8 +3,6 @@
 // host synchronisation, no allocation.
 #include <string.h>
 #include <atomic>
-#include <mutex>
-#include <stdlib.h>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 
@@ -336,51 +334,6 @@ static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int 
     return rc;
 }
 
-// The decode stage on two streams (channels-last heads on the fused route): the largest level (P3:
-// 75 % of the bytes, a pure stream with idle vector units) on the caller's stream, the other
-// levels -- row-max + filter, exact top-k, gather / decode: 80 % of the stage's vector work and all
-// of its dependent launches but three -- on a library-owned high-priority side stream, forked and
-// joined by events.  What is left BEHIND the P3 stream is then its own 1 000 candidates per image
-// instead of all 4 693 (round 4: 25 us of latency / VALU tail behind a 89 us stream).
-// IA_DECODE_SPLIT=0: one stream as before.  One side stream and one event pair per device; the
-// mutex covers the enqueue only (host side, microseconds).
-struct SideStream {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false, ok = false;
-};
-static std::mutex g_side_mu;
-static SideStream g_side[64];
-
-static SideStream *side_stream()          // g_side_mu held
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SideStream &x = g_side[dev];
-    if (!x.tried) {
-        x.tried = true;
-        int lo = 0, hi = 0;                                   // (numerically lowest = highest priority)
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        x.ok = hipStreamCreateWithPriority(&x.st, hipStreamNonBlocking, hi) == hipSuccess &&
-               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-    }
-    return x.ok ? &x : nullptr;
-}
-
-static std::atomic<int> g_decode_split{-1};        // -1: not decided yet (environment), 0 / 1
-
-static bool decode_split_enabled()
-{
-    int v = g_decode_split.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("IA_DECODE_SPLIT");
-        v = (e && e[0] == '0') ? 0 : 1;
-        g_decode_split.store(v, std::memory_order_relaxed);
-    }
-    return v != 0;
-}
-
 static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                                  const float *img_hw, const float *scale_factor, int rescale,
                                  char *ws, hipStream_t s, ia::WsLayout &w, ia::LevelTable &t)
@@ -394,29 +347,6 @@ static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, 
     ia::make_level_table(g, t);
     ia::BaseAnchors ba;
     ia::base_from_geom(g, ba);
-    const int row_split = t.cand_off[1];
-    if (decode_split_enabled() && t.num_levels >= 2 && row_split > 0 && row_split < w.R &&
-        ia::rowmax_select_is_fused(t, *p, batch, dtype)) {
-        std::lock_guard<std::mutex> lock(g_side_mu);
-        if (SideStream *x = side_stream()) {
-            if ((rc = ia::hip_status(hipEventRecord(x->fork, s)))) return rc;
-            if ((rc = ia::hip_status(hipStreamWaitEvent(x->st, x->fork, 0)))) return rc;
-            // side stream: every level but the first
-            rc = ia::launch_rowmax_select(t, *p, batch, dtype, rowmax, cand, ws + w.off[8], x->st, 1, t.num_levels);
-            if (!rc)
-                rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw, scale_factor,
-                                       rescale, boxes, scores_t, best, w.Rs, x->st, row_split, w.R);
-            // caller's stream: the first (largest) level
-            if (!rc) rc = ia::launch_rowmax_select(t, *p, batch, dtype, rowmax, cand, ws + w.off[8], s, 0, 1);
-            if (!rc)
-                rc = ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw, scale_factor,
-                                       rescale, boxes, scores_t, best, w.Rs, s, 0, row_split);
-            // join whatever happened above: the caller's stream never runs ahead of the side stream's work
-            const int rj = ia::hip_status(hipEventRecord(x->join, x->st));
-            const int rw = rj ? rj : ia::hip_status(hipStreamWaitEvent(s, x->join, 0));
-            return rc ? rc : rw;
-        }
-    }
     // row-max (+ group maxima) and the top-k's filter in one launch where the layout allows
     if ((rc = ia::launch_rowmax_select(t, *p, batch, dtype, rowmax, cand, ws + w.off[8], s))) return rc;
     return ia::launch_gather(t, ba, g->means, g->stds, *p, batch, dtype, cand, img_hw, scale_factor,
@@ -462,13 +392,6 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
                    (ia::nms_workspace_bytes(batch, w.R, t.C, noff) + 255) / 256 * 256;
     return ia::launch_finalize(boxes, scores_t, kc, kr, batch, w.R, w.Rs, t.C, max_per_img, fin_ws,
                                dets, labels, rows, num, s, gate);
-}
-
-int ia_debug_decode_split(int mode)
-{
-    if (mode < -1 || mode > 1) return IA_E_ARG;
-    g_decode_split.store(mode, std::memory_order_relaxed);      // -1: back to the environment's choice
-    return 0;
 }
 
 int ia_profile_stage_events(void *begin, void *end)

@@ -327,9 +327,9 @@ __global__ void __launch_bounds__(64 * kGroups) k_gather(GatherArgs a)
     __shared__ float gmax[kGroups][64];
     const int lane = threadIdx.x, grp = threadIdx.y;
     const int b = blockIdx.y;
-    const int r_raw = a.row0 + blockIdx.x * 64 + lane;
-    const bool live = r_raw < a.row1;
-    const int r = live ? r_raw : a.row1 - 1;     // clamp: every thread reaches the barrier
+    const int r_raw = blockIdx.x * 64 + lane;
+    const bool live = r_raw < a.R;
+    const int r = live ? r_raw : a.R - 1;        // clamp: every thread reaches the barrier
     const int A = a.t.A, C = a.t.C;
     const LevelSel lv = level_of_candidate(a, r);
     const int l = lv.l;
@@ -406,14 +406,14 @@ __global__ void __launch_bounds__(1024) k_gather_nhwc(GatherArgs a, int tpc)
     const int tid = threadIdx.x, b = blockIdx.y;
     GPROF(0);
     const int A = a.t.A, C = a.t.C;
-    const int r0 = a.row0 + blockIdx.x * kGTile;
+    const int r0 = blockIdx.x * kGTile;
     const int cand = tid / tpc, w = tid - cand * tpc;          // blockDim.x == kGTile * tpc
     if (tid < kGTile) s_best[tid] = 0u;
     // every thread resolves its candidate itself (the threads of a candidate read the same words:
     // one broadcast request): the only dependent memory round trips of the kernel are
     // candidate index -> {class vectors, IoU logit, box deltas}
     const int r_raw = r0 + cand;
-    const int r = r_raw < a.row1 ? r_raw : a.row1 - 1;
+    const int r = r_raw < a.R ? r_raw : a.R - 1;
     const LevelSel lv = level_of_candidate<MAXL>(a, r);
     const int idx = a.cand_idx[(size_t)b * a.R + r];
     GPROF(1);
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(1024) k_gather_nhwc(GatherArgs a, int tpc)
     const float iou = load_f32<T>(static_cast<const T *>(lv.iou) + row);
     // the first thread of a candidate also decodes its box (a few lanes of every wavefront,
     // ahead of the barrier, rather than one wavefront's worth behind it)
-    const bool boxer = w == 0 && r_raw < a.row1;
+    const bool boxer = w == 0 && r_raw < a.R;
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f, ba0 = 0.0f, ba1 = 0.0f, ba2 = 0.0f, ba3 = 0.0f;
     if (boxer) {
         const T *reg = static_cast<const T *>(lv.reg) + row * 4;
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(1024) k_gather_nhwc(GatherArgs a, int tpc)
     atomicMax(&s_best[cand], to_bits(best));
     __syncthreads();
     GPROF(4);
-    const int nlive = (a.row1 - r0 < kGTile) ? (a.row1 - r0) : kGTile;
+    const int nlive = (a.R - r0 < kGTile) ? (a.R - r0) : kGTile;
     // class-major rows, kGTile contiguous floats each
     float *so = a.scores_t + (size_t)b * C * a.Rs + r0;
     for (int q = tid; q < C * kGTile; q += blockDim.x) {
@@ -471,8 +471,8 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_gather_softmax(GatherArgs a)
 {
     const int b = blockIdx.y;
-    const int r = a.row0 + blockIdx.x * 64 + threadIdx.x;
-    if (r >= a.row1) return;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.R) return;
     const int A = a.t.A, C = a.t.C, Cin = C + 1;
     const LevelSel lv = level_of_candidate(a, r);
     const int W = lv.W, HW = lv.H * W;
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64) k_gather_softmax(GatherArgs a)
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,
-                  float *scores_t, float *best_score, int Rs, hipStream_t s, int row0, int row1)
+                  float *scores_t, float *best_score, int Rs, hipStream_t s)
 {
     if (batch < 1 || !cand_idx || !img_hw || !boxes || !scores_t) return IA_E_ARG;
     if (rescale && !scale_factor) return IA_E_ARG;
@@ -514,13 +514,9 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
     a.cand_idx = cand_idx; a.img_hw = img_hw; a.scale_factor = scale_factor;
     a.boxes = boxes; a.scores_t = scores_t; a.best_score = best_score;
     a.R = t.cand_off[t.num_levels]; a.Rs = Rs; a.rescale = rescale;
-    a.row0 = row0; a.row1 = row1 < 0 ? a.R : row1;
-    if (a.row0 < 0 || a.row1 > a.R || a.row0 > a.row1) return IA_E_ARG;
-    if (a.row0 == a.row1) return 0;
-    const int nrow = a.row1 - a.row0;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
     if (t.softmax) {
-        const dim3 grid((unsigned)((nrow + 63) / 64), (unsigned)batch);
+        const dim3 grid((unsigned)((a.R + 63) / 64), (unsigned)batch);
         if (dtype == IA_F32) hipLaunchKernelGGL(k_gather_softmax<float>, grid, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(k_gather_softmax<uint16_t>, grid, dim3(64), 0, s, a);
         return hip_status(hipGetLastError());
@@ -531,7 +527,7 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
         for (int l = 0; l < t.num_levels; ++l) aligned = aligned && (((uintptr_t)p.cls[l] & 15u) == 0);
         if (aligned) {
             const int vpr = t.C * esz / 16;
-            const dim3 grid((unsigned)((nrow + kGTile - 1) / kGTile), (unsigned)batch);
+            const dim3 grid((unsigned)((a.R + kGTile - 1) / kGTile), (unsigned)batch);
             const size_t lds = (size_t)t.C * (kGTile + 1) * sizeof(float);
             const bool two = vpr % 2 == 0;
             const int tpc = two ? vpr / 2 : vpr;               // threads per candidate
@@ -552,7 +548,7 @@ int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means
         }
     }
     dim3 block(64, kGroups);
-    dim3 grid((unsigned)((nrow + 63) / 64), (unsigned)batch);
+    dim3 grid((unsigned)((a.R + 63) / 64), (unsigned)batch);
     if (dtype == IA_F32) hipLaunchKernelGGL(k_gather<float>, grid, block, 0, s, a);
     else if (dtype == IA_BF16) hipLaunchKernelGGL(k_gather<uint16_t>, grid, block, 0, s, a);
     else return IA_E_ARG;

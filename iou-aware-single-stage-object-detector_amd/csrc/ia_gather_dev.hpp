@@ -19,7 +19,6 @@ struct GatherArgs {
     float *scores_t;
     float *best_score;       // (B, R) max over classes of the fused score (NMS activity filter)
     int32_t R, Rs, rescale;
-    int32_t row0, row1;      // this launch covers the candidate rows [row0, row1) (array strides stay R / Rs)
 };
 
 // delta2bbox of one candidate (reference mmdet/core/bbox/transforms.py:50-76) on the anchor

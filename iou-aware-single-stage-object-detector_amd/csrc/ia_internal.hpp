@@ -132,18 +132,12 @@ int launch_select(const LevelTable &t, const float *rowmax, int batch, int32_t *
 // row-max + top-k the way ia_get_bboxes chains them; channels-last heads: row-max and the top-k
 // filter in ONE launch (select.hip, k_rowmax_filter_nhwc).  The select workspace must have been
 // zeroed once by its owner.
-// lv0 / lv1: only the levels [lv0, lv1) (lv1 < 0: all of them) -- ia_get_bboxes puts the largest
-// level and the rest on two streams
 int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
-                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s,
-                         int lv0 = 0, int lv1 = -1);
-// is the one-launch (fused row-max + filter) route what launch_rowmax_select takes for these outputs?
-bool rowmax_select_is_fused(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype);
+                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s);
 int launch_gather(const LevelTable &t, const BaseAnchors &ba, const float *means, const float *stds,
                   const ia_level_ptrs &p, int batch, int dtype, const int32_t *cand_idx,
                   const float *img_hw, const float *scale_factor, int rescale, float *boxes,
-                  float *scores_t, float *best_score, int Rs, hipStream_t s,
-                  int row0 = 0, int row1 = -1);       // candidate rows [row0, row1) (row1 < 0: all)
+                  float *scores_t, float *best_score, int Rs, hipStream_t s);
 int nms_adj_words(int R);            // 64-bit words per adjacency row (padded)
 size_t nms_workspace_bytes(int batch, int R, int C, size_t off[3]);
 int launch_nms(const float *boxes, const float *scores_t, const float *best_score, int batch,

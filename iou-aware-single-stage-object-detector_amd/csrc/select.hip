@@ -75,7 +75,6 @@ struct SelArgs {
     // waiting writes into the status word, and what k_sel_final compares the word with (a stale
     // word of an earlier call never matches: nothing has to clear it) -- and the spin bound
     uint32_t call_id, spin_limit;
-    int32_t level0;                        // k_sel_final: blockIdx.x = level - level0 (level-range launches)
 };
 
 // The bin d (from the top) where the running count of a 2048-bin histogram reaches `need`, by a
@@ -579,7 +578,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
     __shared__ uint32_t s_red[40];
     uint64_t *sel = s_dyn;                         // p_max + kBucketCap entries
     uint64_t *stage = s_dyn + p_max + kBucketCap;
-    const int l = (int)blockIdx.x + a.level0, b = blockIdx.y;
+    const int l = blockIdx.x, b = blockIdx.y;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     SEL_PROF(1, l, 0);
 
@@ -593,7 +592,7 @@ __global__ void __launch_bounds__(kFinalThreads) k_sel_final(SelArgs a, uint32_t
                              __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.call_id;
     // telemetry (status[1] = calls that fell back): counted by the first workgroup whatever ITS
     // level is -- level 0 need not be a filtered one -- and before the k == n return
-    if (any_timeout && blockIdx.x == 0 && b == 0 && tid == 0) atomicAdd(status + 1, 1u);
+    if (any_timeout && l == 0 && b == 0 && tid == 0) atomicAdd(status + 1, 1u);
     if (k == n) {
         for (uint32_t i = tid; i < n; i += nt) out[i] = (int32_t)i;
         return;
@@ -852,7 +851,6 @@ static int prepare_select(const LevelTable &t, const float *rowmax, int batch, i
     a.cands_per_img = t.cand_off[t.num_levels];
     a.total_chunks = a.plan.chunk_off[IA_MAX_LEVELS];
     a.call_id = 0; a.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
-    a.level0 = 0;
     // LDS of the final kernel: sel (next_pow2 of the largest k) + staged candidates
     uint32_t kmax = 1;
     for (int l = 0; l < t.num_levels; ++l) {
@@ -927,32 +925,8 @@ int launch_groupmax(const LevelTable &t, const float *rowmax, int batch, void *w
 // ia_get_bboxes / ia_decode_stage: row-max + top-k.  Channels-last heads with filtered levels take
 // the fused launch (k_rowmax_filter_nhwc) + k_sel_final; everything else the separate kernels.
 // `workspace` (select workspace) must have been zeroed once by its owner (seg_done).
-static bool fused_allowed()
-{
-    // IA_FUSED_ROWMAX_FILTER=0 in the environment: the separate kernels (A/B runs, bisecting)
-    static const bool allow = [] {
-        const char *e = getenv("IA_FUSED_ROWMAX_FILTER");
-        return !(e && e[0] == '0');
-    }();
-    return allow;
-}
-
-bool rowmax_select_is_fused(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype)
-{
-    if (t.softmax || !fused_allowed() || t.layout != IA_LAYOUT_NHWC || (dtype != IA_F32 && dtype != IA_BF16))
-        return false;
-    const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
-    SelPlan plan;
-    if (make_sel_plan(t, batch, plan) || plan.chunk_off[IA_MAX_LEVELS] <= 0 || t.C % ppl != 0 || t.C / ppl > kMaxVpr)
-        return false;
-    for (int l = 0; l < t.num_levels; ++l)
-        if (((uintptr_t)p.cls[l] & 15u) != 0) return false;
-    return true;
-}
-
 int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch, int dtype,
-                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s,
-                         int lv0, int lv1)
+                         float *rowmax, int32_t *cand_idx, void *workspace, hipStream_t s)
 {
     SelArgs a;
     uint32_t p_max;
@@ -960,16 +934,12 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
     int rc = prepare_select(t, rowmax, batch, cand_idx, workspace, a, p_max, dyn);
     if (rc) return rc;
     if (dtype != IA_F32 && dtype != IA_BF16) return IA_E_ARG;
-    if (lv1 < 0) lv1 = t.num_levels;
-    if (lv0 < 0 || lv1 > t.num_levels || lv0 >= lv1) return IA_E_ARG;
-    const bool ranged = lv0 != 0 || lv1 != t.num_levels;
     const int ppl = (dtype == IA_F32) ? Lane<float>::PPL : Lane<uint16_t>::PPL;
     // IA_FUSED_ROWMAX_FILTER=0 in the environment: the separate kernels (A/B runs, bisecting)
     static const bool allow_fused = [] {
         const char *e = getenv("IA_FUSED_ROWMAX_FILTER");
         return !(e && e[0] == '0');
     }();
-    if (ranged && !rowmax_select_is_fused(t, p, batch, dtype)) return IA_E_ARG;   // level ranges: fused route only
     if (t.softmax) {            // softmax row scores (decode.hip), then the separate selection kernels
         rc = launch_rowmax(t, p, batch, dtype, rowmax, s);
         if (rc) return rc;
@@ -1007,16 +977,16 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
         };
         auto chunks = [&](int l) { return (int64_t)(a.plan.chunk_off[l + 1] - a.plan.chunk_off[l]); };
         for (int l = 0; l < IA_MAX_LEVELS; ++l) fo.units[l] = 0;
-        for (int l = lv0; l < lv1; ++l) {
+        for (int l = 0; l < t.num_levels; ++l) {
             const int64_t units = (int64_t)batch * sel_units_per_image(t, l);
             if (units > 2147483647LL) return IA_E_ARG;
             fo.units[l] = (int32_t)units;
             if ((rc = push(l, 0, (units + 3) / 4))) return rc;
-            if (l > lv0 && chunks(l - 1) > 0 && (rc = push(l - 1, 1, batch))) return rc;
+            if (l > 0 && chunks(l - 1) > 0 && (rc = push(l - 1, 1, batch))) return rc;
         }
-        const int last = lv1 - 1;
+        const int last = t.num_levels - 1;
         if (chunks(last) > 0 && (rc = push(last, 1, batch))) return rc;
-        for (int l = lv0; l < lv1; ++l)
+        for (int l = 0; l < t.num_levels; ++l)
             if (chunks(l) > 1 && (rc = push(l, 2, (chunks(l) - 1) * batch))) return rc;
         fo.n_items = it;
         for (; it < 3 * IA_MAX_LEVELS; ) { fo.item_level[it] = 0; fo.item_filter[it] = 0; fo.item_off[++it] = (int32_t)blocks; }
@@ -1041,8 +1011,7 @@ int launch_rowmax_select(const LevelTable &t, const ia_level_ptrs &p, int batch,
     }
     rc = hip_status(hipGetLastError());
     if (!rc) {
-        a.level0 = lv0;
-        hipLaunchKernelGGL(k_sel_final, dim3((unsigned)(lv1 - lv0), (unsigned)batch),
+        hipLaunchKernelGGL(k_sel_final, dim3((unsigned)t.num_levels, (unsigned)batch),
                            dim3(kFinalThreads), dyn, s, a, p_max);
         rc = hip_status(hipGetLastError());
     }

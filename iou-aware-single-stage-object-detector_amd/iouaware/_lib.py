@@ -93,7 +93,6 @@ SIGNATURES = {
     'ia_decode_stage': (_i, [_G, _P, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     'ia_get_bboxes_status_offset': (_sz, [_G, _i]),
     'ia_debug_fused_spin_limit': (_i, [_i64]),
-    'ia_debug_decode_split': (_i, [_i]),
     'ia_profile_stage_events': (_i, [_vp, _vp]),
     'ia_gather_decode': (_i, [_G, _P, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'ia_multiclass_nms_workspace_bytes': (_sz, [_i, _i, _i]),

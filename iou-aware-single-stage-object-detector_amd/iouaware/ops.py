@@ -206,11 +206,6 @@ def fused_spin_limit(limit=-1):
     _lib.check(_lib.lib().ia_debug_fused_spin_limit(int(limit)), 'ia_debug_fused_spin_limit')
 
 
-def decode_split(mode=-1):
-    """the decode stage on two streams (ia_debug_decode_split): 1 on, 0 off, -1 the default again"""
-    _lib.check(_lib.lib().ia_debug_decode_split(int(mode)), 'ia_debug_decode_split')
-
-
 def stage_events(begin=None, end=None):
     """ia_profile_stage_events: the decode stage of every later get_bboxes / DecodeStage call records
     these two torch.cuda.Event(enable_timing=True) objects on its stream (in front of the row-max

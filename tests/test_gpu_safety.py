@@ -196,48 +196,3 @@ def test_stage_events_bracket_the_decode_stage_and_change_nothing(ops):
     ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)
     torch.cuda.synchronize()
     assert e0.elapsed_time(e1) == stage_ms
-
-
-@pytest.mark.parametrize('kind,dtype', [('A', torch.float32), ('C', torch.float32), ('A', torch.bfloat16)])
-def test_decode_stage_on_two_streams_equals_one_stream(ops, oracle_lib, kind, dtype):
-    """ia_get_bboxes puts the largest level on the caller's stream and the other levels on a
-    library-owned side stream (fork / join by events inside the call).  Same bits as the one-stream
-    stage at every stage output, call after call with the next call's inputs being overwritten in
-    between (a missing join would let the caller's stream run ahead of the side stream), and
-    image 0 against the oracle."""
-    ph, pw, B = 800, 1344, 4
-    geom, base = G.geometry(ph, pw, 1000)
-    cls, reg, iou = synth.head_outputs(91, B, ph, pw, kind)
-    if dtype == torch.bfloat16:
-        cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
-    dev = [[t.contiguous(memory_format=torch.channels_last) for t in G.to_dev(x, dtype)] for x in (cls, reg, iou)]
-    assert ops.geometry_for(geom, *dev).layout == 1
-    shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
-    keys = ('rowmax', 'cand_idx', 'boxes', 'scores_t', 'keep_count')
-    try:
-        ops.decode_split(0)
-        one = ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100, debug=True)
-        one = [t.clone() for t in one[:4]] + [{k: one[4][k].clone() for k in keys}]
-        ops.decode_split(1)
-        scratch = [[torch.empty_like(t) for t in x] for x in dev]
-        for it in range(12):
-            two = ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100, debug=True)
-            for a, b in zip(one[:4], two[:4]):
-                assert torch.equal(a, b), 'iteration %d' % it
-            for k in keys:
-                assert torch.equal(one[4][k], two[4][k]), (k, it)
-            # the product entry (lazy NMS) right behind it on other inputs, then back
-            for x in scratch:
-                for t in x:
-                    t.normal_()
-            ops.get_bboxes(geom, *scratch, shapes, sfs, True, 0.05, 0.5, 100)
-        lazy = ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)
-        for a, b in zip(one[:4], lazy):
-            assert torch.equal(a, b)
-    finally:
-        ops.decode_split(-1)
-    o = oracle_lib.get_bboxes_single([x[0] for x in cls], [x[0] for x in reg], [x[0] for x in iou], synth.STRIDES,
-                                     base, (800, 1333), 1.0, True, 1000, 0.05, 0.5, 100)
-    n = int(one[3][0])
-    assert n == o['num_det'] and G.same_bits(one[0][0, :n].cpu().numpy(), o['det_bboxes'])
-    assert np.array_equal(one[2][0, :n].cpu().numpy(), o['det_rows'])
