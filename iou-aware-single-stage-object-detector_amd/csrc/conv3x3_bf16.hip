@@ -275,35 +275,9 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
 #undef CV_STORE_A
 #undef CV_LOAD_B
 
-    // ---- epilogue: C block (i, j): column n = lane & 31, row m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int odd = lane & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nt * kCvBN + wn * 64 + j * 32 + (lane & 31);          // channel inside the group
-        const bool n_ok = (n - odd) + 1 < a.Cout;                             // the pair this lane stores (Cout is even)
-        const float bz = (a.bias && n < a.Cout) ? a.bias[grp * a.Cout + n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float v0 = acc[i][j][r] + bz, v1 = acc[i][j][r + 1] + bz;
-                if (a.relu) { v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; }
-                // even lane keeps row r and takes the odd neighbour's row-r value (channel n + 1);
-                // odd lane keeps row r + 1 and takes the even neighbour's (channel n - 1)
-                const float give = odd ? v0 : v1;
-                const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-                const int rr = odd ? r + 1 : r;
-                const int m = wm * kWM + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
-                const uint32_t lo = bf16_rne(odd ? got : v0), hi = bf16_rne(odd ? v1 : got);
-                if (m < tile_px) {
-                    const int ty = m / TW, tx = m - ty * TW;
-                    const int oy = y0 + ty, ox = x0 + tx;
-                    if (oy < H && ox < W && n_ok)
-                        *reinterpret_cast<uint32_t *>(a.y[grp][lv] + (((size_t)b * H + oy) * W + ox) * a.ys + (n - odd)) = lo | (hi << 16);
-                }
-            }
-        }
-    }
+    // ---- epilogue (ia_conv3.hpp)
+    conv3_store_tile<MB>(acc, a, a.y[grp][lv] + (size_t)b * H * W * a.ys, wm * kWM, nt * kCvBN + wn * 64,
+                         grp * a.Cout, H, W, TW, y0, x0, tile_px, lane);
 }
 
 // weights (groups * Cout, 3, 3, Cin) bf16 -> [groups][ceil(Cout / 256)][Cin / 32][9] steps of 256 x 32

@@ -102,7 +102,18 @@ def test_ddp_over_the_fused_training_route_on_rccl_one_rank():
         dist.destroy_process_group()
 
 
-def _run_ranks(world, extra_env=None, iters=25, timeout=420):
+def _run_ranks(world, extra_env=None, iters=25, timeout=420, attempts=3):
+    """(a rendezvous port that was free a moment ago can be taken by the time rank 0 binds it:
+    EADDRINUSE is retried on another port)"""
+    for k in range(attempts):
+        try:
+            return _run_ranks_once(world, extra_env, iters, timeout)
+        except AssertionError as exc:
+            if 'EADDRINUSE' not in str(exc) or k == attempts - 1:
+                raise
+
+
+def _run_ranks_once(world, extra_env, iters, timeout):
     import json
     import subprocess
     import sys
@@ -122,6 +133,9 @@ def _run_ranks(world, extra_env=None, iters=25, timeout=420):
             for q in procs:
                 q.kill()
             raise
+        if p.returncode != 0:
+            for q in procs:
+                q.kill()
         assert p.returncode == 0, (out[-1000:], err[-3000:])
         recs.append(json.loads([l for l in out.splitlines() if l.startswith('{')][-1]))
     return recs
