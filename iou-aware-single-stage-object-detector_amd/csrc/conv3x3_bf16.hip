@@ -182,10 +182,10 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
     __syncthreads();
     bf16x8 fr0, fr1, fr2, fr3;                // PIPE: ring of four fragments, read three MFMA pairs ahead
     if constexpr (PIPE == 2) {
-        static_assert(PIPE != 2 || MB == 4, "the fragment ring is laid out for four pixel blocks");
+        static_assert(PIPE != 2 || MB == 4 || MB == 2, "the fragment ring is laid out for four or two pixel blocks");
         fr0 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[0]);
         fr1 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[1 % MB]);
-        fr2 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[2 % MB]);
+        fr2 = *reinterpret_cast<const bf16x8 *>(s_a[0] + a_off[MB == 4 ? 2 : 0] + (MB == 4 ? 0 : 32));
     }
 
     // One step: the MFMAs of (chunk, TAP): A from the patch (a tap only shifts the read window), B
@@ -234,7 +234,14 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
             const bf16x8 g00 = __builtin_bit_cast(bf16x8, X0), g10 = __builtin_bit_cast(bf16x8, X2); \
             const bf16x8 g01 = __builtin_bit_cast(bf16x8, X1), g11 = __builtin_bit_cast(bf16x8, X3); \
             /* pair p = (kk, block i) uses ring slot p & 3; in front of it the fragment of pair p + 3 \
-               is requested (pairs 8, 9, 10 = the next step's first three) */                       \
+               is requested (pairs 8, 9, 10 = the next step's first three; with two blocks a step  \
+               has four pairs and pairs 4, 5, 6 are the next step's) */                             \
+            if constexpr (MB == 2) {                                                                \
+            CV_PAIR(fr3, ab + a_off[1 % MB] + 32, fr0, 0, g00, g10)                                 \
+            CV_PAIR(fr0, abn + a_off[0], fr1, 1 % MB, g00, g10)                                     \
+            CV_PAIR(fr1, abn + a_off[1 % MB], fr2, 0, g01, g11)                                     \
+            CV_PAIR(fr2, abn + a_off[0] + 32, fr3, 1 % MB, g01, g11)                                \
+            } else {                                                                                \
             CV_PAIR(fr3, ab + a_off[3 % MB], fr0, 0, g00, g10)                                      \
             CV_PAIR(fr0, ab + a_off[0] + 32, fr1, 1 % MB, g00, g10)                                 \
             CV_PAIR(fr1, ab + a_off[1 % MB] + 32, fr2, 2 % MB, g00, g10)                            \
@@ -243,6 +250,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
             CV_PAIR(fr0, abn + a_off[0], fr1, 1 % MB, g01, g11)                                     \
             CV_PAIR(fr1, abn + a_off[1 % MB], fr2, 2 % MB, g01, g11)                                \
             CV_PAIR(fr2, abn + a_off[2 % MB], fr3, 3 % MB, g01, g11)                                \
+            }                                                                                       \
         } else {                                                                                    \
             CV_MFMA(0, X0, X2)                                                                      \
             CV_MFMA(1, X1, X3)                                                                      \
@@ -435,8 +443,12 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
         // IA_CONV3_PIPE=0: the (4, 1, 4) variant without the fragment ring (A/B runs)
         static const int pipe = [] { const char *e = getenv("IA_CONV3_PIPE"); return e ? atoi(e) : 2; }();
+        // ... and the (2, 1, 4) variant's (168 registers: still three wavefronts per SIMD; 50 x 84 at batch
+        // 16 0.090 -> 0.087 ms, the backbone's 256 -> 256 / 512 -> 512 layers 0.091 -> 0.088 / 0.097 -> 0.094)
+        static const int pipe21 = [] { const char *e = getenv("IA_CONV3_PIPE21"); return e ? atoi(e) : 1; }();
         if (wnc == 4 && mb == 4 && pipe == 2) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4, 2>), grid, dim3(256), 0, st, a);
         else if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
+        else if (wnc == 4 && pipe21) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4, 2>), grid, dim3(256), 0, st, a);
         else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
         else if (mb == 1 && wnk == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 4, 1>), grid, dim3(256), 0, st, a);
         else if (mb == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 2, 2>), grid, dim3(256), 0, st, a);
