@@ -582,7 +582,9 @@ int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, i
  * pix_stride (elements) may exceed the map's own channel count: reg / iou may be channel slices
  * of one wider tensor.  C % 4 == 0; cls / reg pointers and strides 16-byte aligned.  g->layout is
  * not consulted.  Gradients are written with their own pixel strides (e.g. into the slices of one
- * tensor shaped like the wider one).                                                        */
+ * tensor shaped like the wider one).  When grads->iou[l] lies right behind grads->reg[l] in the same
+ * pixel row (iou == reg + 4 A, equal strides) the backward also writes the zero gradient of the
+ * row's remaining channels (stride - 5 A of them, alignment padding): the caller need not clear it. */
 typedef struct ia_level_pix_strides {
     int64_t cls[IA_MAX_LEVELS], reg[IA_MAX_LEVELS], iou[IA_MAX_LEVELS];
 } ia_level_pix_strides;

@@ -1,23 +1,25 @@
 // 3x3 / stride 1 / pad 1 convolution on bf16 channels-last tensors, fp32 accumulation, bias (+ReLU)
-// epilogue: the head-tower / FPN-output shape of BASELINE config 3 (R-101 bf16, reference
-// iou_aware_retina_head.py:171-219 `ConvModule(256, 256, 3, padding=1)`, conv_module.py:149-163).
-// An implicit GEMM on v_mfma_f32_32x32x16_bf16: M = the pixels of a spatial tile, N = 256 output
-// channels, K = 9 taps x Cin.
+// epilogue: the head-tower / FPN-output / bottleneck shape of BASELINE config 3 (R-101 bf16, reference
+// iou_aware_retina_head.py:171-219 `ConvModule(256, 256, 3, padding=1)`, conv_module.py:149-163,
+// resnet.py:215-255).  An implicit GEMM on v_mfma_f32_32x32x16_bf16: M = the pixels of a spatial tile,
+// N = up to 256 output channels, K = 9 taps x Cin.
 //
-//  * A workgroup (8 wavefronts, 2 x 4) owns a TH x TW pixel tile (TH * TW <= 256; the tile shape is
-//    picked per feature map so that the tiles cover it with little overhang: 10 x 24 for 100 x 168,
-//    9 x 28 for 50 x 84 ...) and 256 output channels; a wavefront 128 pixels x 64 channels
-//    = 4 x 2 accumulator blocks of 32 x 32.
+//  * A workgroup = four wavefronts as WM x WN, each 32 * MB pixels x 64 output channels (MB x 2
+//    accumulator blocks of 32 x 32); it owns a TH x TW pixel tile (64 or 128 pixels; the shape is picked
+//    per feature map for the least overhang) and 64 * WN channels.  Two or three workgroups share a CU,
+//    so one's prologue and epilogue run under the others' K loops.
 //  * K loop: Cin in chunks of 32.  The (TH + 2) x (TW + 2) halo patch of a chunk goes to LDS ONCE
-//    and serves all nine taps as shifted windows (a tap only moves the wavefront's read offset):
-//    1.3 reads of the activation instead of an im2col GEMM's 9.  The weights of (chunk, tap) --
-//    256 x 32, packed contiguously by ia_conv3x3_bf16_pack -- are double-buffered in LDS; the next
-//    tile's global loads are issued before the MFMAs of the current one.
-//  * LDS rows (a pixel's / an output channel's 32 k-values = 64 bytes) are padded to 80 bytes: the
-//    16 lanes of a ds_read_b128 group then start in 16 different 16-byte bank slots.
-//  * Epilogue from the accumulators: + bias, ReLU, round to bf16; neighbouring lanes hold
-//    neighbouring output channels of one pixel, so lane pairs swap one value (DPP) and store
-//    4 bytes each, 64-byte runs per pixel.
+//    (double-buffered: requested at tap 2, stored at tap 6) and serves all nine taps as shifted windows:
+//    1.3 reads of the activation instead of an im2col GEMM's 9.
+//  * The weights never touch LDS: ia_conv3x3_bf16_pack stores them in FRAGMENT order, a wavefront's four
+//    B fragments of a step are four 1-KiB-contiguous loads straight into registers (three register
+//    sets in rotation, requested two steps ahead).
+//  * LDS rows (a pixel's 32 k-values = 64 bytes) are padded to 80 bytes and the patch's row pitch is
+//    TW + 16 pixels: the 16 lanes of every ds_read_b128 service group start in 16 different bank slots.
+//  * PIPE = 2 (both Cout > 128 variants): the A fragments run through a ring of four registers, read
+//    three MFMA pairs ahead of their use.
+//  * Epilogue (ia_conv3.hpp): + bias, ReLU, one rounding to bf16 (v_cvt_pk_bf16_f32); lane pairs swap one
+//    value (DPP) and store 4 bytes each, 64-byte runs per pixel; rows advance by additions.
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -74,7 +76,9 @@ __device__ __forceinline__ uint32_t bf16_rne(float f)
 // batch 16: 0.312 -> 0.300 ms; counters: matrix pipe 0.53 -> 0.59 busy, and the chip answers with 1.67
 // instead of 1.80 GHz (profiles/r05_conv3x3_bf16_pmc.txt): busy x clock, i.e. throughput, +2.4 %.
 template <int MB, int WM, int WN, int PIPE = 0>
-__global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(Conv3Args a)
+// (waves per SIMD asked for: 2 for the 128 / 256-accumulator variants; the (1, 4, 1) variant's two 25 KiB
+// patch buffers allow three workgroups per CU, (1, 2, 2) with its 64-pixel patches four)
+__global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? (WM == 4 ? 3 : 4) : 2) k_conv3x3_bf16(Conv3Args a)
 {
     constexpr int kThreads = 64 * WM * WN;
     static_assert(MB * WM == 4 || MB * WM == 2, "128- or 64-pixel tiles");
@@ -98,13 +102,22 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
     const int nchunk = a.Cin / kCvBK, nsteps = nchunk * 9;
 
     // ---- this lane's A rows (pixels) as byte offsets into the patch (tap (0,0) corner)
+    // (one vector division per lane; the blocks 32 pixels further on by additions and a wrap test --
+    // 32 = q32 * TW + r32 with scalar q32, r32: the prologue's dozen vector integer divisions were
+    // ~400 instructions of every workgroup's life)
     int a_off[MB];
+    {
+        const int q32 = 32 / TW, r32 = 32 - q32 * TW;
+        const int m0 = wm * kWM + (lane & 31);
+        int ty = m0 / TW, tx = m0 - ty * TW;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        int m = wm * kWM + mb * 32 + (lane & 31);
-        m = m < tile_px ? m : tile_px - 1;                // idle rows read a valid address
-        const int ty = m / TW, tx = m - ty * TW;
-        a_off[mb] = (ty * PWl + tx) * kCvRow + (lane >> 5) * 16;
+        for (int mb = 0; mb < MB; ++mb) {
+            const bool idle = m0 + mb * 32 >= tile_px;    // idle rows read a valid address: the tile's last pixel
+            const int ry = idle ? TH - 1 : ty, rx = idle ? TW - 1 : tx;
+            a_off[mb] = (ry * PWl + rx) * kCvRow + (lane >> 5) * 16;
+            tx += r32; ty += q32;
+            if (tx >= TW) { tx -= TW; ++ty; }
+        }
     }
 
     // ---- global -> register staging (plain scalars and macros: arrays captured by a lambda went
@@ -118,13 +131,18 @@ __global__ void __launch_bounds__(64 * WM * WN, MB == 1 ? 4 : 2) k_conv3x3_bf16(
     const uint16_t *pa0, *pa1, *pa2, *pa3;
     int sa_off0, sa_off1, sa_off2, sa_off3;                // LDS byte offsets of the pieces
     bool in0, in1, in2, in3, on0, on1, on2, on3;
+    // piece u of a thread = patch pixel (tid >> 2) + u * (kThreads / 4): row / column by additions from
+    // piece 0's (one vector division)
+    const int pq = (kThreads / 4) / PW, pr = (kThreads / 4) - pq * PW;
+    int ppy = (tid >> 2) / PW, ppx = (tid >> 2) - ppy * PW;
 #define CV_PIECE(u, PA, IN, ON, SA)                                                                 \
     {                                                                                               \
-        int p = u * kThreads + tid;                                                                 \
+        const int p = u * kThreads + tid;                                                           \
         ON = p < npix * 4;                                                                          \
-        p = ON ? p : 0;                                                                             \
-        const int px = p >> 2, part = p & 3;                                                        \
-        const int py = px / PW, pxx = px - py * PW;                                                 \
+        const int part = p & 3;                                                                     \
+        const int py = ON ? ppy : 0, pxx = ON ? ppx : 0;                                            \
+        ppx += pr; ppy += pq;                                                                       \
+        if (ppx >= PW) { ppx -= PW; ++ppy; }                                                        \
         const int iy = y0 + py - 1, ix = x0 + pxx - 1;                                              \
         IN = ON && iy >= 0 && iy < H && ix >= 0 && ix < W;                                      \
         const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix); \
@@ -441,15 +459,11 @@ int ia_conv3x3_bf16_levels(const ia_conv3x3_desc *d, const void *wp, const float
         a.L = n;
         for (int l = n; l <= IA_MAX_LEVELS; ++l) a.tile_off[l] = (int32_t)tiles;
         const dim3 grid((unsigned)tiles, (unsigned)(d->groups * a.ntile));
-        // IA_CONV3_PIPE=0: the (4, 1, 4) variant without the fragment ring (A/B runs)
-        static const int pipe = [] { const char *e = getenv("IA_CONV3_PIPE"); return e ? atoi(e) : 2; }();
-        // ... and the (2, 1, 4) variant's (168 registers: still three wavefronts per SIMD; 50 x 84 at batch
-        // 16 0.090 -> 0.087 ms, the backbone's 256 -> 256 / 512 -> 512 layers 0.091 -> 0.088 / 0.097 -> 0.094)
-        static const int pipe21 = [] { const char *e = getenv("IA_CONV3_PIPE21"); return e ? atoi(e) : 1; }();
-        if (wnc == 4 && mb == 4 && pipe == 2) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4, 2>), grid, dim3(256), 0, st, a);
-        else if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4>), grid, dim3(256), 0, st, a);
-        else if (wnc == 4 && pipe21) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4, 2>), grid, dim3(256), 0, st, a);
-        else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4>), grid, dim3(256), 0, st, a);
+        // both Cout > 128 variants with the fragment ring (PIPE = 2; the (2, 1, 4) variant at 168 registers:
+        // still three wavefronts per SIMD; 50 x 84 at batch 16 0.090 -> 0.087 ms, the backbone's 256 -> 256 /
+        // 512 -> 512 layers 0.091 -> 0.088 / 0.097 -> 0.094)
+        if (wnc == 4 && mb == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<4, 1, 4, 2>), grid, dim3(256), 0, st, a);
+        else if (wnc == 4) hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 1, 4, 2>), grid, dim3(256), 0, st, a);
         else if (mb == 1 && wnk == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 4, 1>), grid, dim3(256), 0, st, a);
         else if (mb == 1) hipLaunchKernelGGL((ia::k_conv3x3_bf16<1, 2, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((ia::k_conv3x3_bf16<2, 2, 2>), grid, dim3(256), 0, st, a);

@@ -580,6 +580,7 @@ struct BoxNhwcArgs {
     float means[4], stds[4];
     float beta, lw_bbox, lw_iou;
     int32_t attach;
+    int32_t g_pad[IA_MAX_LEVELS];         // bwd: zero-gradient channels behind d(iou) in the same pixel row
 };
 
 template <bool BWD>
@@ -633,6 +634,10 @@ __global__ void __launch_bounds__(256) k_box_nhwc(BoxNhwcArgs a)
             *reinterpret_cast<float4 *>(a.g_reg[l] + pix * a.pg_reg[l] + 4 * an) =
                 make_float4(g_box[0], g_box[1], g_box[2], g_box[3]);
             a.g_iou[l][pix * a.pg_iou[l] + an] = g_iou;
+            // d(reg) | d(iou) as slices of one wider tensor: its alignment channels behind the IoU
+            // slice get their zero gradient here (the last anchor's thread), not from a fill per level
+            if (an == A - 1)
+                for (int k = 0; k < a.g_pad[l]; ++k) a.g_iou[l][pix * a.pg_iou[l] + A + k] = 0.0f;
         }
     }
     if (!BWD) {
@@ -980,6 +985,7 @@ int ia_head_loss_fwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * kNumLoss * (size_t)L * IA_LOSS_SLOTS, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((k_focal_nhwc<false>), dim3((unsigned)fa.lv.fblk_off[L]), dim3(256), 0, s, fa);
+    for (int l = 0; l < IA_MAX_LEVELS; ++l) ba.g_pad[l] = 0;
     hipLaunchKernelGGL((k_box_nhwc<false>), dim3((unsigned)fa.lv.bblk_off[L]), dim3(256), 0, s, ba);
     FinArgs f;
     f.sums = sums; f.counts = t->counts; f.avg_dev = t->avg_factor_dev; f.avg_host = t->avg_factor;
@@ -1027,6 +1033,11 @@ int ia_head_loss_bwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
         ba.bt[l] = on ? t->bbox_targets[l] : nullptr; ba.bw[l] = on ? t->bbox_weights[l] : nullptr;
         ba.g_reg[l] = on ? (float *)grads->reg[l] : nullptr;
         ba.g_iou[l] = on ? (float *)grads->iou[l] : nullptr;
+        // both gradients in one pixel row (iou right behind reg): the channels left up to the row's end
+        ba.g_pad[l] = 0;
+        if (on && ba.g_iou[l] == ba.g_reg[l] + 4 * fa.lv.A && ba.pg_reg[l] == ba.pg_iou[l] &&
+            ba.pg_reg[l] > 5 * fa.lv.A && ba.pg_reg[l] - 5 * fa.lv.A <= 64)
+            ba.g_pad[l] = (int32_t)(ba.pg_reg[l] - 5 * fa.lv.A);
     }
     fa.sums = nullptr; fa.gin = grad_result; fa.res = result;
     fa.big_logits = 0;

@@ -1598,10 +1598,12 @@ class _HeadLossNhwcFn(torch.autograd.Function):
         if ctx.fused:
             # one gradient tensor per level shaped like the wider tensor; channels beyond reg | iou
             # (alignment padding) get zero gradient
+            # (the backward kernel writes the zero gradient of those channels itself when, as here, the
+            # iou slice follows the reg slice in the pixel row: ia_head_loss_bwd_nhwc)
             g_base = [torch.empty(b.shape, dtype=torch.float32, device=dev, memory_format=cl)
                       for b in bases]
             for l, b in enumerate(bases):
-                if b.shape[1] > reg[l].shape[1] + iou[l].shape[1]:
+                if b.shape[1] - (reg[l].shape[1] + iou[l].shape[1]) > 64:
                     g_base[l].zero_()
             for l in range(L):
                 gp.reg[l] = g_base[l].data_ptr() + (reg[l].data_ptr() - bases[l].data_ptr())

@@ -82,3 +82,29 @@ def test_conv3x3_bf16_levels_groups_slices_and_odd_widths():
         want = torch.nn.functional.conv2d(a[:, :F].double(), wc.double(), bc.double(), 1, 1)
         err = (o.double() - want).abs()
         assert bool((err <= 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())).all()), float(err.max())
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_conv3x3_bf16_random_shapes(seed):
+    """seeded random maps / channel counts / batches through every variant the launcher picks (tile
+    shapes with wraps inside a 32-pixel block, narrow maps, partial column tiles, Cout from 2 to 600,
+    Cin in 32-channel chunks): against the fp64 convolution of the bf16-rounded operands"""
+    import numpy as np
+    from iouaware import ops
+    rs = np.random.RandomState(1000 + seed)
+    B = int(rs.randint(1, 5))
+    H, W = int(rs.randint(1, 70)), int(rs.randint(1, 90))
+    ci = 32 * int(rs.randint(1, 9))
+    co = 2 * int(rs.choice([1, 8, 17, 32, 45, 64, 100, 128, 150, 256, 300]))
+    relu, bias = bool(rs.randint(0, 2)), bool(rs.randint(0, 2))
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.randn(B, ci, H, W, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, 3, 3, device='cuda', generator=g) * (2.0 / (9 * ci)) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(co, device='cuda', generator=g) if bias else None
+    y = ops.conv3x3_bf16(x, ops.conv3x3_bf16_pack(w), b, co, relu=relu)
+    want = torch.nn.functional.conv2d(x.double(), w.double(), b.double() if bias else None, 1, 1)
+    if relu:
+        want = want.clamp(min=0)
+    err = (y.double() - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 2e-3 * float(want.abs().max()) * 2.0 ** -8
+    assert bool((err <= tol).all()), (B, H, W, ci, co, float(err.max()), float(want.abs().max()))

@@ -7,10 +7,10 @@
 # Output: gpurun_out/pmc/mfma_pmc.json (per kernel name, averaged over its launches).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp; export TMPDIR=/tmp
-python $ROOT/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-train > /dev/null 2>&1      # warm MIOpen's find db
+python $ROOT/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-train --no-other-configs > /dev/null 2>&1      # warm MIOpen's find db
 rm -rf /tmp/pmc_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma -- \
-    python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train > /tmp/pmc_mfma.log 2>&1
+    python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train --no-other-configs > /tmp/pmc_mfma.log 2>&1
 mkdir -p $ROOT/gpurun_out/pmc
 python - <<PY
 import csv, glob, json, collections

@@ -10,10 +10,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train > /tmp/warm.log 2>&1   # warms MIOpen's find db
+python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-train --no-other-configs > /tmp/warm.log 2>&1   # warms MIOpen's find db
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- \
-    python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train > /tmp/prof_bench.log 2>&1
+    python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train --no-other-configs --no-pipeline > /tmp/prof_bench.log 2>&1
 grep "^{" /tmp/prof_bench.log > $OUT/bench.json
 head -60 /tmp/prof_bench/*/*_kernel_stats.csv | cut -c1-260 > $OUT/kernel_stats.csv
 grep "ia::" /tmp/prof_bench/*/*_kernel_stats.csv > $OUT/kernel_stats_ia.csv
