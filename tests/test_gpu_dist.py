@@ -174,3 +174,18 @@ def test_fused_launch_on_a_quarter_of_the_chip():
     if os.path.isdir(out):
         with open(os.path.join(out, 'oversubscription_report.txt'), 'a') as fh:
             fh.write('2 ranks, HSA_CU_MASK=0:0-63: %s\\n' % recs)
+
+
+def test_pin_rank_reads_the_real_topology():
+    """the rank -> cores plan on THIS host's sysfs (not applied): the GPU's PCI address resolves to a
+    NUMA node (or -1 in a VM), the plan is a non-empty subset of the allowed cores, two ranks that
+    would share the GPU's node get disjoint shares"""
+    from iouaware import dist as idist
+    allowed = os.sched_getaffinity(0)
+    r0 = idist.pin_rank(0, 2, device_count=1, apply=False)
+    r1 = idist.pin_rank(1, 2, device_count=1, apply=False)
+    assert 'error' not in r0 and 'error' not in r1, (r0, r1)
+    assert r0['pinned'] is False and r0['cpus'] >= 1 and r0['cpus'] <= len(allowed)
+    assert isinstance(r0['numa_node'], int) and r0['numa_node'] >= -1
+    print('\n[pin_rank] rank 0 of 2: %s' % r0)
+    print('[pin_rank] rank 1 of 2: %s' % r1)
