@@ -72,7 +72,7 @@ class Bf16ConvHead(object):
 
     def _acts(self, name, feats, channels):
         key = (name, channels, tuple(tuple(x.shape) for x in feats), feats[0].device,
-               torch.cuda.current_stream().cuda_stream)
+               ops.stream_id())
         a = self._bufs.get(key)
         if a is None:
             # ping-pong activations of ONE pad shape (4 names); real evaluation sees many pad shapes

@@ -46,24 +46,40 @@ def _fold_bn(bn):
     return scale.contiguous(), shift.contiguous()
 
 
-def _stamp(module):
-    """identity + version of what the folded copies were derived from: every convolution weight
-    and one running statistic per BatchNorm under `module`.  An optimizer step, a checkpoint
-    load (in-place copies bump `_version`) or `.to(device / dtype)` (new storage) changes it."""
-    out = []
+def _stamp_slots(module):
+    """where the tensors of `_stamp` live: (parameter / buffer dict, key) pairs -- a dict lookup per
+    forward instead of a walk over the submodules through nn.Module.__getattr__ (32 us per fused module
+    and forward: a third of a batch-1 step's host time, which is what bounds that step)"""
+    slots = []
     # a ResNet's own folded copies derive from its stem only (the blocks below are fused modules
-    # with their own stamps): do not walk ~160 modules per forward, and do not re-fold the frozen
-    # stem because a trainable stage took an optimizer step
+    # with their own stamps): do not re-fold the frozen stem because a trainable stage took an
+    # optimizer step
     scope = (module.conv1, module.norm1) if isinstance(module, ResNet) else (module,)
     for m in (sub for top in scope for sub in top.modules()):
         if isinstance(m, torch.nn.Conv2d):
-            out.append((m.weight.data_ptr(), m.weight._version))
+            slots.append((m._parameters, 'weight'))
             if m.bias is not None:
-                out.append((m.bias.data_ptr(), m.bias._version))
+                slots.append((m._parameters, 'bias'))
         elif isinstance(m, _BatchNorm) and m.running_var is not None:
-            out.append((m.running_var.data_ptr(), m.running_var._version))
+            slots.append((m._buffers, 'running_var'))
             if m.weight is not None:
-                out.append((m.weight.data_ptr(), m.weight._version))
+                slots.append((m._parameters, 'weight'))
+    return slots
+
+
+def _stamp(module):
+    """identity + version of what the folded copies were derived from: every convolution weight
+    and one running statistic per BatchNorm under `module`.  An optimizer step, a checkpoint
+    load (in-place copies bump `_version`) or `.to(device / dtype)` (new storage, also a new buffer
+    object: the slots are looked up in the modules' own dicts every time) changes it.  The module
+    structure itself is fixed once fused (fuse_inference / unfuse_inference rebuild the slots)."""
+    slots = module.__dict__.get('_ia_stamp_slots')
+    if slots is None:
+        slots = module.__dict__['_ia_stamp_slots'] = _stamp_slots(module)
+    out = []
+    for d, k in slots:
+        t = d[k]
+        out.append((t.data_ptr(), t._version) if t is not None else (0, 0))
     return tuple(out)
 
 
@@ -526,6 +542,7 @@ def _fold(m):
         m._ia_fused = f
     else:
         return False
+    m.__dict__.pop('_ia_stamp_slots', None)         # (re)fold: the slots are rebuilt from the module as it is now
     m._ia_stamp = _stamp(m)
     m._ia_dirty = False
     return True
@@ -605,7 +622,7 @@ def unfuse_inference(model):
         if hasattr(m, '_ia_layer'):
             del m._ia_layer
             m.__dict__.pop('forward', None)
-        for attr in ('_ia_fused', '_ia_wino', '_ia_c3', '_ia_opts', '_ia_stamp', '_ia_dirty'):
+        for attr in ('_ia_fused', '_ia_wino', '_ia_c3', '_ia_opts', '_ia_stamp', '_ia_dirty', '_ia_stamp_slots'):
             if hasattr(m, attr):
                 delattr(m, attr)
                 for name in ('forward', '_stem', '_stages'):

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, stream_id
 
 _G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
                [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
@@ -67,7 +67,7 @@ def _scratch(device, name, shape):
     n = 1
     for d in shape:
         n *= int(d)
-    key = (device, torch.cuda.current_stream().cuda_stream, name)
+    key = (device, stream_id(), name)
     b = _SCRATCH.get(key)
     if b is None or b.numel() < n:
         b = _SCRATCH[key] = torch.empty(n, dtype=torch.float32, device=device)
@@ -213,7 +213,7 @@ class WinogradConv3x3(object):
         BatchNorm / ReLU is applied while the input transform loads it"""
         # the plan owns scratch buffers (V, M): one per stream, so forwards on different streams
         # do not share them
-        key = (x.shape[0], tuple(x.shape[-2:]), x.device, torch.cuda.current_stream().cuda_stream)
+        key = (x.shape[0], tuple(x.shape[-2:]), x.device, stream_id())
         plan = _plan_for(self._plans, key, lambda: _Plan([tuple(x.shape[-2:])], x.shape[0], x.device))
         v = input_transform(plan, [x], 1, plan.buf('v', (36, plan.T, self.cin)), pre)
         m = batched_gemm(v, self.u, plan.buf('m', (36, plan.T, self.cout)))
@@ -279,7 +279,7 @@ class WinogradHead(object):
         """feats: per-level (B, Cin, H, W) channels-last fp32 -> (cls[L], reg[L], iou[L])"""
         B = feats[0].shape[0]
         sizes = [tuple(x.shape[-2:]) for x in feats]
-        key = (B, tuple(sizes), feats[0].device, torch.cuda.current_stream().cuda_stream)
+        key = (B, tuple(sizes), feats[0].device, stream_id())
         plan = _plan_for(self._plans, key, lambda: _Plan(sizes, B, feats[0].device))
         T, F = plan.T, self.F
         # layer 0

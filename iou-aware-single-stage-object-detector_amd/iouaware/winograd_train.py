@@ -35,7 +35,7 @@ from . import winograd as W
 
 def _plan(xs):
     key = (xs[0].shape[0], tuple(tuple(x.shape[-2:]) for x in xs), xs[0].device,
-           torch.cuda.current_stream().cuda_stream)
+           W.stream_id())
     return W._plan_for(_PLANS, key, lambda: W._Plan([tuple(x.shape[-2:]) for x in xs], xs[0].shape[0],
                                                     xs[0].device))
 
