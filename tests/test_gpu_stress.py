@@ -348,3 +348,36 @@ def test_serving_threads_with_their_own_streams():
     for th in threads:
         th.join()
     assert not errs, errs[:5]
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_softmax_get_bboxes_random_configurations(oracle_lib, seed):
+    """the use_sigmoid_cls=False branch (iou_aware_retina_head.py:506-507,540-541) over random pyramid
+    sizes, class counts (whole 16-byte rows or not), batches, nms_pre (none / tiny / large), thresholds
+    and score statistics incl. saturated logits: every stage bit for bit against the oracle through
+    check_against_oracle (both memory orders, complete and lazy NMS)"""
+    import test_gpu_parity as P
+    from iouaware import ops
+    rs = np.random.RandomState(9000 + seed)
+    ph, pw = 32 * int(rs.randint(2, 9)), 32 * int(rs.randint(2, 11))
+    B = int(rs.randint(1, 4))
+    Cf = int(rs.choice([79, 80, 19, 3]))                   # 80 / 20 class channels: whole vectors; 81 / 4: not
+    nms_pre = int(rs.choice([-1, 17, 300, 1000]))
+    sd = float(rs.choice([1.0, 2.5, 12.0]))                # 12: softmax saturates, many exact ties at 0 / 1
+    dtype = torch.float32 if rs.randint(0, 3) else torch.bfloat16
+    cls, reg, iou = [], [], []
+    for (h, w) in synth.level_shapes(ph, pw):
+        c = (rs.standard_normal((B, synth.A, Cf + 1, h, w)) * sd).astype(np.float32)
+        c[:, :, 0] += np.float32(rs.uniform(0.0, 3.0))
+        cls.append(np.ascontiguousarray(c.reshape(B, synth.A * (Cf + 1), h, w)))
+        reg.append((rs.standard_normal((B, synth.A * 4, h, w)) * 0.5).astype(np.float32))
+        iou.append((rs.standard_normal((B, synth.A, h, w)) * 1.5).astype(np.float32))
+    if dtype == torch.bfloat16:
+        cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
+    _, base = G.geometry(ph, pw, nms_pre)
+    geom = ops.HeadGeometry(synth.level_shapes(ph, pw), synth.STRIDES, base, Cf, nms_pre=nms_pre, softmax=True)
+    metas = [synth.img_meta(ph - int(rs.randint(0, 9)), pw - int(rs.randint(0, 9)), ph, pw,
+                            float(rs.choice([1.0, 1.37]))) for _ in range(B)]
+    P.check_against_oracle(ops, oracle_lib, cls, reg, iou, geom, base, metas, bool(rs.randint(0, 2)),
+                           float(rs.choice([0.02, 0.05, 0.3])), float(rs.choice([0.3, 0.5])),
+                           int(rs.choice([10, 100])), dtype=dtype)
