@@ -53,6 +53,9 @@ def _build(backbone=None):
 def _prepare(m, path):
     from iouaware.fuse import fuse_inference
     m = m.cuda()
+    # (library paths: ask the framework for its deterministic convolution algorithms -- MIOpen's fast
+    # grouped / strided fp32 kernels add split-K partial sums with atomics)
+    torch.backends.cudnn.deterministic = path in ('module', 'fused')
     if path == 'fused':
         assert fuse_inference(m) > 0
     elif path == 'winograd':
@@ -109,7 +112,7 @@ def _relerr(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
-def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
+def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None, keys=None):
     """Every reference detection without a counterpart within TOL must have a stated reason, or
     the test fails (round 2 accepted `matched >= total - 2 / - 5` without looking at WHICH ones):
       closer-to-truth  (`truth`: the same detector evaluated in fp64, per-class arrays) the
@@ -123,6 +126,10 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
       near-cut  its score lies within 8 x the measured head-logit error (relative) of the
                 reference's 100th score: rank 100 / 101 may swap (`gaps`: the fixture's own
                 relative gaps between consecutive survivors, when it stores them).
+    `keys` (a list) receives one (class, score rounded to 4 places, reason) per explained miss: the
+    bench path is bit-reproducible, so its set of explained misses is a CONSTANT and the tests
+    compare it with the committed FROZEN_MISSES; `near=0` switches the
+    near-tol hatch off.
     -> (lines for the report, number unexplained)"""
     scores = np.concatenate([w[:, 4] for w in want if len(w)]) if any(len(w) for w in want) else np.zeros(0)
     cut = float(scores.min()) if scores.size else 0.0
@@ -152,13 +159,19 @@ def _explain_unmatched(want, got, logit_err, gaps=None, near=2.0, truth=None):
                     lines.append('class %d score %.4f: own detection off the reference by %.2f x TOL, off the fp64 '
                                  'evaluation by %.2f x TOL; the REFERENCE is off its own fp64 evaluation by %.2f x '
                                  'TOL (closer-to-truth)' % (c, d[4], near / TOL, e_own.max() / TOL, e_ref.max() / TOL))
+                    if keys is not None:
+                        keys.append((c, round(float(d[4]), 4), 'closer-to-truth'))
                     continue
             if near <= near_tol_mult * TOL:
                 lines.append('class %d score %.4f: nearest own detection off by %.2f x TOL (near-tol)'
                              % (c, d[4], near / TOL))
+                if keys is not None:
+                    keys.append((c, round(float(d[4]), 4), 'near-tol'))
             elif rel_to_cut <= margin:
                 lines.append('class %d score %.6f: %.1e above the cut score, margin %.1e (near-cut)'
                              % (c, d[4], rel_to_cut, margin))
+                if keys is not None:
+                    keys.append((c, round(float(d[4]), 4), 'near-cut'))
             else:
                 lines.append('class %d score %.4f box %s: UNEXPLAINED (nearest %.2e, %.1e above the cut)'
                              % (c, d[4], d[:4].tolist(), near, rel_to_cut))
@@ -183,32 +196,44 @@ _REPORT = []
 _HATCHES = []          # (fixture, path / image, number of explained misses): printed with the report
 
 
-def _hatch_budget(tag, why, allowed):
-    """the number of EXPLAINED misses is capped per fixture -- 0 for the R-50
-    fixtures (BASELINE configs 1 / 2), at most 1 for the ~110-layer backbones on this build's own
-    kernels (2 on the plain-module path, which is the framework's non-reproducible library
-    convolutions) -- so the hatch count cannot grow silently; the count goes into the parity report."""
-    _HATCHES.append((tag, len(why)))
-    assert len(why) <= allowed, '%s: %d explained misses, %d allowed: %s' % (tag, len(why), allowed, why)
+# the bench path (Winograd transforms + frozen-table hipBLASLt GEMMs + own kernels) computes
+# the same bits in every run (tests/test_gpu_determinism.py), so WHICH reference detections it misses within
+# 1e-4 -- and why -- is a constant of (fixture, weights).  The constant is committed here: a new miss fails, a
+# vanished miss fails.  (fixture, path) -> [(class, score, reason)]; absent = none.  near-tol is not a reason
+# on this path.
+FROZEN_MISSES = {
+}
+LIBRARY_PATHS = ('module', 'fused')     # convolutions by the framework's library: not reproducible run to run
 
+
+def _hatches(tag, why, keys, frozen_key=None):
+    """the explained misses of one comparison go into the parity report; on the bench path they must EQUAL the
+    committed list, on a library path they are reported only (the caller asserts `bad == 0`: VERDICT r5 1a)"""
+    _HATCHES.append((tag, len(why)))
+    if frozen_key is not None:
+        want = sorted(FROZEN_MISSES.get(frozen_key, []))
+        assert sorted(keys) == want, '%s: explained misses %s, frozen list %s: %s' % (tag, sorted(keys), want, why)
 
 
 @pytest.fixture(scope='module', autouse=True)
 def _print_report():
+    """(tests of this file are collected in two groups -- bench path early, library paths last, see conftest.py --
+    so this runs more than once: the report accumulates and the file is rewritten with everything so far)"""
     yield
     if _REPORT:
+        lines = list(_REPORT)
         if _HATCHES:
-            _REPORT.append('tolerance hatches used (explained misses; cap 0 on the R-50 fixtures, 1 per '
-                           'fixture on the deeper backbones): %d in total over %d comparisons -- %s'
-                           % (sum(n for _, n in _HATCHES), len(_HATCHES),
-                              ', '.join('%s: %d' % h for h in _HATCHES if h[1]) or 'none'))
+            lines.append('tolerance hatches used (explained misses; bench path: equal to the frozen list, '
+                         'library paths: reported): %d in total over %d comparisons -- %s'
+                         % (sum(n for _, n in _HATCHES), len(_HATCHES),
+                            ', '.join('%s: %d' % h for h in _HATCHES if h[1]) or 'none'))
         print('\n[e2e parity report]')
-        for line in _REPORT:
+        for line in lines:
             print('  ' + line)
         out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
         if os.path.isdir(out):
             with open(os.path.join(out, 'e2e_parity_report.txt'), 'w') as fh:
-                fh.write('\n'.join(_REPORT) + '\n')
+                fh.write('\n'.join(lines) + '\n')
 
 
 @pytest.mark.parametrize('path', PATHS)
@@ -275,16 +300,23 @@ def test_image_to_detections_matches_reference(golden_dir, name, path):
     assert n_got == n
     # every reference detection must be matched, or be explained (tolerance touched / rank 100
     # vs 101 within the measured head-output error); kept anchor ids may differ only by as many
-    why, bad = _explain_unmatched(want, result, worst, f['det_score_gaps'])
+    library = path in LIBRARY_PATHS
+    keys = []
+    why, bad = _explain_unmatched(want, result, worst, f['det_score_gaps'], near=2.0 if library else 0.0,
+                                  keys=keys)
     for line in why:
         _REPORT.append('      %s %s: %s' % (name, path, line))
     assert bad == 0, why
     assert matched + len(why) == total
-    # configs 1 / 2 (R-50): 100 / 100 within 1e-4 with NO hatch, asserted
-    _hatch_budget('r50 %s %s' % (name, path), why, 0)
-    assert same_ids == len(theirs), (same_ids, len(theirs))
+    # configs 1 / 2 (R-50) on the bench path: 100 / 100 within 1e-4, NO explained miss, identical kept anchor
+    # ids -- asserted.  Library paths (MIOpen convolutions, a few 1e-6 different from run to run): every miss must
+    # be explained (`bad == 0` above); how many there are is reported, not gated.
+    _hatches('r50 %s %s' % (name, path), why, keys, None if library else ('r50_' + name, path))
+    if not library:
+        assert same_ids == len(theirs), (same_ids, len(theirs))
 
 
+@pytest.mark.module_path
 def test_reference_call_signature_variants(golden_dir):
     """forward_test's argument checks and the batch-of-one return convention
     (base.py:85-103, single_stage.py:96)"""
@@ -354,11 +386,62 @@ def _trained_like(m, seed=11):
     return m
 
 
-@pytest.mark.parametrize('name,backbone', [
+DEEP = [
     ('r101', dict(depth=101)),
     ('x101_64x4d', dict(type='ResNeXt', depth=101, groups=64, base_width=4)),
     ('x101_32x4d', dict(type='ResNeXt', depth=101, groups=32, base_width=4)),
-])
+]
+
+
+@pytest.mark.parametrize('name,backbone', DEEP)
+def test_deeper_backbones_bench_path_matches_fp64_evaluation(name, backbone):
+    """R-101 (config 3's backbone) and X-101-64x4d / 32x4d (config 4; grouped 3x3 convolutions on the MFMA
+    kernel of csrc/gconv.hip, reference resnext.py:12-91) on the bench's path against the SAME modules
+    evaluated in fp64 on the host -- a partner that is the same in every run (the plain fp32 modules on the GPU
+    are not: VERDICT r5 item 1a; that comparison is `..._fused_paths_match_module_path`, collected last).
+    Every head logit within 1e-4 of the fp64 value; the detections of the bench path against the detections the
+    product's post-conv path makes of the fp64 logits: matched one to one within 1e-4, explained misses equal to
+    the committed list."""
+    import copy
+    from iouaware.bbox import bbox2result
+    from iouaware.fuse import fuse_inference
+    m = _trained_like(_build(backbone))
+    x_cpu = torch.from_numpy(synth.e2e_image(9, 2, 256, 320, 256, 320))
+    metas = [synth.img_meta(256, 320, 256, 320, 1.0)] * 2
+    with torch.no_grad():
+        m64 = copy.deepcopy(m).double()
+        truth_head = m64.bbox_head(m64.extract_feat(x_cpu.double()))
+        del m64
+    m = m.cuda()
+    with torch.no_grad():
+        th = [[t.float().cuda() for t in ts] for ts in truth_head]
+        truth_dets = [m.bbox_head.get_bboxes(*[[t[b:b + 1] for t in ts] for ts in th], None, None,
+                                             metas[b:b + 1], m.test_cfg, True)[0] for b in range(2)]
+        truth_dets = [bbox2result(d, l, 81) for d, l in truth_dets]
+        fuse_inference(m, winograd=True)
+        m = m.to(memory_format=torch.channels_last)
+        xc = x_cpu.cuda().contiguous(memory_format=torch.channels_last)
+        wino = m.forward_head(xc)
+        wino_dets = m.simple_test_batch(xc, metas, rescale=True)
+    worst = 0.0
+    for a, b in zip(truth_head, wino):
+        for u, v in zip(a, b):
+            worst = max(worst, float(_relerr(v.float().cpu().numpy(), u.numpy()).max()))
+    assert worst <= TOL, (name, worst)
+    for b, (d, t) in enumerate(zip(wino_dets, truth_dets)):
+        matched, total, wb, ws = _match_sets(t, d)
+        keys = []
+        why, bad = _explain_unmatched(t, d, worst, near=0.0, keys=keys)
+        _REPORT.append('%-10s image %d: bench path vs the fp64 evaluation: head logits %.2f x TOL | dets %d/%d within '
+                       '1e-4 (worst box %.2e, score %.2e)' % (name, b, worst / TOL, matched, total, wb, ws))
+        for line in why:
+            _REPORT.append('      %s image %d: %s' % (name, b, line))
+        assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
+        _hatches('%s image %d (bench path vs fp64)' % (name, b), why, keys, (name + '_img%d' % b, 'vs-fp64'))
+
+
+@pytest.mark.module_path
+@pytest.mark.parametrize('name,backbone', DEEP)
 def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
     """R-101 (config 3's backbone) and X-101-64x4d (config 4; its grouped 3x3 convs run on the
     MFMA kernel of csrc/gconv.hip in the channels-last path, reference resnext.py:12-91): fused
@@ -413,7 +496,7 @@ def test_deeper_backbones_fused_paths_match_module_path(name, backbone):
         assert total > 0 and bad == 0 and matched + len(why) == total, (name, matched, total, why)
         # (the comparison partner here is the plain-module path = the framework's library convolutions,
         # not reproducible from run to run around the tolerance: two, like the module-path fixtures)
-        _hatch_budget('%s image %d (bench path vs plain modules)' % (name, b), why, 2)
+        _hatches('%s image %d (bench path vs plain modules)' % (name, b), why, [])
 
 
 @pytest.mark.parametrize('path', ['module', 'winograd'])
@@ -477,50 +560,24 @@ def test_deeper_backbones_match_the_reference(golden_dir, name, backbone, path):
     # evaluation (the reference's own fp32 result is at least as far from it), near-tol <= 2 x TOL,
     # or rank 100 / 101 within the measured logit error -- no count-based slack, no widened band
     # (round 3: 3 x TOL; the X-101-64x4d reference fixture itself is 0.70 x TOL off its fp64 twin).
-    why, bad = _explain_unmatched(want, result, worst, near=2.0, truth=truth)
+    library = path in LIBRARY_PATHS
+    keys = []
+    why, bad = _explain_unmatched(want, result, worst, near=2.0 if library else 0.0, truth=truth, keys=keys)
     for line in why:
         _REPORT.append('      %s %s: %s' % (name, path, line))
     assert total == 100 and bad == 0 and matched + len(why) == total, (matched, total, why)
-    # the bench path (own kernels: the same bits in every run) gets ONE; the plain-module path runs the
-    # framework's library convolutions, whose grouped / strided kernels add with atomics and differ from
-    # run to run by a few 1e-5 around the tolerance (round 5: 1 miss in one run, 2 in the next on the
-    # X-101-64x4d fixture, all inside the fp64 triangulation): two there
-    _hatch_budget('%s %s (vs the reference)' % (name, path), why, 1 if path != 'module' else 2)
+    # the bench path (own kernels: the same bits in every run): the explained misses EQUAL the committed list;
+    # the plain-module path runs the framework's library convolutions, whose grouped / strided kernels add with
+    # atomics and differ from run to run by a few 1e-5 around the tolerance (round 5: 1, 2 and 3 misses in
+    # three runs of the X-101-64x4d fixture, all inside the fp64 triangulation): reported, `bad == 0` gates
+    _hatches('%s %s (vs the reference)' % (name, path), why, keys, None if library else (name, path))
     # (reported, not asserted: the distance of the product path from the fp64 evaluation.  The
     # north star's bar is the reference; on the 256x320 X-101-64x4d fixture one ill-conditioned
     # box -- exp(dw) on a 400 px anchor amplifies a 0.15 x TOL logit difference eightfold -- puts
     # the reference 0.70 and this build 1.26 x TOL from the truth, 0.56 x TOL from each other.)
 
 
-def test_config3_bf16_batch16_post_conv_path(oracle_lib):
-    """BASELINE config 3's per-GPU shape: 16 images, bf16 head outputs at 800x1344,
-    channels-last.  Image 0 and image 15 bit for bit against the oracle fed the same
-    bf16-rounded logits; batch invariance for a middle image."""
-    from iouaware import ops
-    ph, pw, B = 800, 1344, 16
-    geom, base = G.geometry(ph, pw, 1000)
-    cls, reg, iou = synth.head_outputs(777, B, ph, pw, 'C')
-    cls, reg, iou = G.bf16_round(cls), G.bf16_round(reg), G.bf16_round(iou)
-    dev = [[t.contiguous(memory_format=torch.channels_last) for t in G.to_dev(x, torch.bfloat16)]
-           for x in (cls, reg, iou)]
-    assert ops.geometry_for(geom, *dev).layout == 1
-    shapes, sfs = [(800, 1333, 3)] * B, [1.0] * B
-    dets, labels, rows, num = [t.cpu().numpy() for t in
-                               ops.get_bboxes(geom, *dev, shapes, sfs, True, 0.05, 0.5, 100)]
-    for b in (0, 15):
-        o = oracle_lib.get_bboxes_single([x[b] for x in cls], [x[b] for x in reg],
-                                         [x[b] for x in iou], synth.STRIDES, base, (800, 1333),
-                                         1.0, True, 1000, 0.05, 0.5, 100)
-        n = int(num[b])
-        assert n == o['num_det'] and n > 0
-        assert np.array_equal(rows[b, :n], o['det_rows'])
-        assert np.array_equal(labels[b, :n], o['det_labels'])
-        assert G.same_bits(dets[b, :n], o['det_bboxes'])
-    b = 7
-    one = [t.cpu().numpy() for t in ops.get_bboxes(geom, *[[t[b:b + 1] for t in x] for x in dev],
-                                                   shapes[:1], sfs[:1], True, 0.05, 0.5, 100)]
-    assert int(one[3][0]) == int(num[b]) and np.array_equal(one[0][0], dets[b])
-    assert np.array_equal(one[2][0], rows[b])
+# (config 3's post-conv path at batch 16 -- bf16 logits against the oracle -- lives in tests/test_gpu_configs.py)
 
 
 def _stage_outputs(m, x):
