@@ -556,6 +556,15 @@ typedef struct ia_head_loss_cfg {
     int32_t exact_large_logits;                  /* class logits > 60: the loss VALUE of such a negative
                                                     element saturates at 60 unless this is set (one more
                                                     pass over the logits); gradients are exact either way */
+    int32_t grad_rows_start_at_reg;              /* ia_head_loss_bwd_nhwc only.  The caller STATES that in every
+                                                    level grads->reg[l] is channel 0 of its pixel row of
+                                                    grad_strides->reg[l] floats and grads->iou[l] == grads->reg[l]
+                                                    + 4 A in the same row; the backward then also writes the zero
+                                                    gradient of the row's remaining stride - 5 A (<= 64) channels.
+                                                    0 (e.g. a row laid out [X | reg | iou | pad]): only the reg /
+                                                    iou slices are written, the caller clears the rest.  Nothing is
+                                                    inferred from the pointers alone.  Zero-initialise
+                                                    this struct: it has grown since round 4.               */
 } ia_head_loss_cfg;
 
 /* workspace (256-byte aligned, ia_head_loss_workspace_bytes): the fp64 partial sums and an
@@ -582,9 +591,11 @@ int ia_head_loss_bwd(const ia_head_geom *g, const ia_level_ptrs *p, int dtype, i
  * pix_stride (elements) may exceed the map's own channel count: reg / iou may be channel slices
  * of one wider tensor.  C % 4 == 0; cls / reg pointers and strides 16-byte aligned.  g->layout is
  * not consulted.  Gradients are written with their own pixel strides (e.g. into the slices of one
- * tensor shaped like the wider one).  When grads->iou[l] lies right behind grads->reg[l] in the same
- * pixel row (iou == reg + 4 A, equal strides) the backward also writes the zero gradient of the
- * row's remaining channels (stride - 5 A of them, alignment padding): the caller need not clear it. */
+ * tensor shaped like the wider one).  With cfg->grad_rows_start_at_reg set -- reg is channel 0 of the
+ * gradient's pixel row, iou right behind it (iou == reg + 4 A, equal strides; IA_E_ARG when the pointers
+ * contradict the flag) -- the backward also writes the zero gradient of the row's remaining channels
+ * (stride - 5 A of them, alignment padding) and the caller need not clear them; without the flag it writes
+ * the reg / iou slices and nothing else. */
 typedef struct ia_level_pix_strides {
     int64_t cls[IA_MAX_LEVELS], reg[IA_MAX_LEVELS], iou[IA_MAX_LEVELS];
 } ia_level_pix_strides;

@@ -3,6 +3,7 @@
 // host synchronisation, no allocation.
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include "ia_internal.hpp"
 #include "ia_math.hpp"
 
@@ -302,9 +303,11 @@ int ia_get_bboxes_workspace_layout(const ia_head_geom *g, int batch, size_t offs
 // library, so the first stage call after installation binds it; ia_profile_stage_events(NULL,
 // NULL) unbinds): calls on other streams / from other models in the process do not record into the
 // same events.  The caller clears the hook before releasing the events.
-static std::atomic<void *> g_stage_ev[2];
-static std::atomic<void *> g_stage_stream{nullptr};
-static std::atomic<int> g_stage_bound{0};
+// (events, binding flag and bound stream were four separate atomics -- a caller on another
+// stream could compare with a stale stream, or see the old begin event with the new end event.  One small
+// mutex around the whole record: the hook is read once per stage call, ~20 ns uncontended.)
+static std::mutex g_stage_mu;
+static struct { void *ev[2]; void *stream; bool bound; } g_stage = {{nullptr, nullptr}, nullptr, false};
 
 static int decode_stage_launches(const ia_head_geom *g, const ia_level_ptrs *p, int batch, int dtype,
                                  const float *img_hw, const float *scale_factor, int rescale,
@@ -321,12 +324,13 @@ static int decode_stage_impl(const ia_head_geom *g, const ia_level_ptrs *p, int 
     if (workspace_bytes < w.total) return IA_E_WORKSPACE;
     if (((uintptr_t)workspace & 255u) != 0) return IA_E_ARG;
     char *ws = static_cast<char *>(workspace);
-    hipEvent_t e0 = (hipEvent_t)g_stage_ev[0].load(std::memory_order_acquire);
-    hipEvent_t e1 = (hipEvent_t)g_stage_ev[1].load(std::memory_order_acquire);
-    if (e0) {
-        int unbound = 0;
-        if (g_stage_bound.compare_exchange_strong(unbound, 1)) g_stage_stream.store((void *)s, std::memory_order_release);
-        else if (g_stage_stream.load(std::memory_order_acquire) != (void *)s) e0 = e1 = nullptr;   // another stream's call
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        if (g_stage.ev[0]) {
+            if (!g_stage.bound) { g_stage.bound = true; g_stage.stream = (void *)s; }
+            if (g_stage.stream == (void *)s) { e0 = (hipEvent_t)g_stage.ev[0]; e1 = (hipEvent_t)g_stage.ev[1]; }
+        }                                                           // else: another stream's call records nothing
     }
     if (e0 && (rc = ia::hip_status(hipEventRecord(e0, s)))) return rc;
     rc = decode_stage_launches(g, p, batch, dtype, img_hw, scale_factor, rescale, ws, s, w, t);
@@ -397,10 +401,9 @@ static int get_bboxes_impl(const ia_head_geom *g, const ia_level_ptrs *p, int ba
 int ia_profile_stage_events(void *begin, void *end)
 {
     if ((begin == nullptr) != (end == nullptr)) return IA_E_ARG;
-    g_stage_ev[0].store(nullptr, std::memory_order_release);        // no call records a half-updated pair
-    g_stage_ev[1].store(end, std::memory_order_release);
-    g_stage_bound.store(0, std::memory_order_release);              // the next stage call binds its stream
-    g_stage_ev[0].store(begin, std::memory_order_release);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    g_stage.ev[0] = begin; g_stage.ev[1] = end;
+    g_stage.bound = false; g_stage.stream = nullptr;                // the next stage call binds its stream
     return 0;
 }
 

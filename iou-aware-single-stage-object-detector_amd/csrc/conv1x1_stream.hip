@@ -53,15 +53,23 @@ __global__ void __launch_bounds__(kC1Threads) __attribute__((amdgpu_waves_per_eu
     // weight fragment of (step s = 4 j + c, block nb): s_w[(16 j + 4 q + c) * LDW + nb * 16 + p_in]
     const float *wq = s_w + (4 * q) * LDW + p_in;
     for (int tile = wave; tile < a.tiles; tile += nwaves) {
-        const int64_t p0 = (int64_t)tile * 16 + p_in;
-        const int64_t p = p0 < a.P ? p0 : a.P - 1;         // clamped: loads unconditional
-        const float *xr = a.x + p * K + 4 * q;
+        // rows are 32-bit here (the entry point refuses more than 2^31 - 16 of them: 64 channels x 4 bytes x 2^31
+        // rows would be 550 GB): the clamp is one v_min_i32 against an SGPR -- the 64-bit select kept a VGPR copy
+        // of (P - 1)'s high word alive across the loop, the one register the budget did not have
+        const int p0 = tile * 16 + p_in, plast = (int)a.P - 1;
+        const int64_t p = p0 < plast ? p0 : plast;          // clamped: loads unconditional
+        // (the lane's column offset goes through an empty asm: otherwise `a.res + 4 q` and `a.y + 4 q` are hoisted
+        // out of the tile loop as two more 64-bit per-lane values, and with 64 accumulator + 16 activation + 8
+        // fragment registers live the 128-register budget was 4 short: two scratch reloads per tile)
+        int q4 = 4 * q;
+        asm volatile("" : "+v"(q4));
+        const float *xr = a.x + (p * K + q4);
         f32x4 xv[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4 *>(xr + 16 * j);
         f32x4 acc[NB];
         if (a.res) {
-            const float *rr = a.res + p * N + 4 * q;
+            const float *rr = a.res + (p * N + q4);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rr + 16 * nb));
         } else {
@@ -79,18 +87,25 @@ __global__ void __launch_bounds__(kC1Threads) __attribute__((amdgpu_waves_per_eu
             for (int c = 0; c < 4; ++c) {
                 const float xb = xv[j][c];
                 const float *wrow = wq + (16 * j + c) * LDW;
-                float wf[NB];
+                // (fragments in batches of at most 8: with all 16 of a 256-wide step live next to the 64
+                // accumulator registers the 128-register budget of 4 waves / SIMD was 4-6 registers short)
+                constexpr int WB = NB > 8 ? 8 : NB;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = wrow[16 * nb];
+                for (int n0 = 0; n0 < NB; n0 += WB) {
+                    float wf[WB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < WB; ++nb) wf[nb] = wrow[16 * (n0 + nb)];
+#pragma unroll
+                    for (int nb = 0; nb < WB; ++nb)
+                        acc[n0 + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[n0 + nb], 0, 0, 0);
+                    if (n0 + WB < NB) __builtin_amdgcn_sched_barrier(0);
+                }
                 // the fragment reads of a later step must not climb above this point: fully
                 // unrolled, the scheduler hoisted all K * N / 64 of them and spilled
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if (p0 < a.P) {
-            float *yr = a.y + p * N + 4 * q;
+        if (p0 <= plast) {
+            float *yr = a.y + (p * N + q4);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 f32x4 v = acc[nb];
@@ -161,12 +176,19 @@ __global__ void __launch_bounds__(kWideThreads) __attribute__((amdgpu_waves_per_
             for (int c = 0; c < 4; ++c) {
                 const float xb = xv[j][c];
                 const float *wrow = wq + (16 * j + c) * LDW;
-                float wf[NB];
+                // (fragments in batches of at most 8: with all 16 of a 256-wide step live next to the 64
+                // accumulator registers the 128-register budget of 4 waves / SIMD was 4-6 registers short)
+                constexpr int WB = NB > 8 ? 8 : NB;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = wrow[16 * nb];
+                for (int n0 = 0; n0 < NB; n0 += WB) {
+                    float wf[WB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < WB; ++nb) wf[nb] = wrow[16 * (n0 + nb)];
+#pragma unroll
+                    for (int nb = 0; nb < WB; ++nb)
+                        acc[n0 + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[n0 + nb], 0, 0, 0);
+                    if (n0 + WB < NB) __builtin_amdgcn_sched_barrier(0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         if (p0 < a.P) {
@@ -249,12 +271,19 @@ __global__ void __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per
             for (int c = 0; c < 4; ++c) {
                 const float xb = xv[j][c];
                 const float *wrow = wq + (16 * j + c) * LDW;
-                float wf[NB];
+                // (fragments in batches of at most 8: with all 16 of a 256-wide step live next to the 64
+                // accumulator registers the 128-register budget of 4 waves / SIMD was 4-6 registers short)
+                constexpr int WB = NB > 8 ? 8 : NB;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) wf[nb] = wrow[16 * nb];
+                for (int n0 = 0; n0 < NB; n0 += WB) {
+                    float wf[WB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < WB; ++nb) wf[nb] = wrow[16 * (n0 + nb)];
+#pragma unroll
+                    for (int nb = 0; nb < WB; ++nb)
+                        acc[n0 + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb], xb, acc[n0 + nb], 0, 0, 0);
+                    if (n0 + WB < NB) __builtin_amdgcn_sched_barrier(0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         // y = relu(acc): stored, and the operand of the second product
@@ -345,7 +374,7 @@ extern "C" int ia_conv1x1_stream(const float *x, const float *w, const float *bi
     a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y; a.P = rows; a.relu = relu ? 1 : 0;
     a.xs = a.ws = a.ys = 0;
     const int64_t tiles = (rows + 15) / 16;
-    if (tiles > 2147483647LL) return IA_E_ARG;
+    if (rows > 2147483647LL - 16) return IA_E_ARG;          // k_conv1x1_stream indexes rows with 32 bits
     a.tiles = (int32_t)tiles;
     int64_t wgs = (tiles + 7) / 8;
     if (wgs > 512) wgs = 512;                              // two resident workgroups per CU, tiles strided over the wavefronts
@@ -371,7 +400,7 @@ extern "C" int ia_batched_gemm_stream(const float *A, const float *W, float *D, 
     a.x = A; a.w = W; a.bias = nullptr; a.res = nullptr; a.y = D; a.P = rows; a.relu = 0;
     a.xs = rows * k; a.ws = (int64_t)k * n; a.ys = rows * n;
     const int64_t tiles = (rows + 15) / 16;
-    if (tiles > 2147483647LL) return IA_E_ARG;
+    if (rows > 2147483647LL - 16) return IA_E_ARG;          // k_conv1x1_stream indexes rows with 32 bits
     a.tiles = (int32_t)tiles;
     int64_t wgs = (tiles + 7) / 8;                         // every matrix gets its share of the 512 resident workgroups
     const int64_t share = (512 + batch - 1) / batch;

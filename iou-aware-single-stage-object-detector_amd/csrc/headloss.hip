@@ -1033,11 +1033,16 @@ int ia_head_loss_bwd_nhwc(const ia_head_geom *g, const ia_level_ptrs *p,
         ba.bt[l] = on ? t->bbox_targets[l] : nullptr; ba.bw[l] = on ? t->bbox_weights[l] : nullptr;
         ba.g_reg[l] = on ? (float *)grads->reg[l] : nullptr;
         ba.g_iou[l] = on ? (float *)grads->iou[l] : nullptr;
-        // both gradients in one pixel row (iou right behind reg): the channels left up to the row's end
+        // both gradients in one pixel row that STARTS at reg (the caller says so: cfg->grad_rows_start_at_reg;
+        // a row [X | reg | iou | pad] looks the same from here, and zero-filling behind iou would run into the
+        // next pixel's X): the channels left up to the row's end get their zero gradient here
         ba.g_pad[l] = 0;
-        if (on && ba.g_iou[l] == ba.g_reg[l] + 4 * fa.lv.A && ba.pg_reg[l] == ba.pg_iou[l] &&
-            ba.pg_reg[l] > 5 * fa.lv.A && ba.pg_reg[l] - 5 * fa.lv.A <= 64)
+        if (on && cfg->grad_rows_start_at_reg) {
+            if (ba.g_iou[l] != ba.g_reg[l] + 4 * fa.lv.A || ba.pg_reg[l] != ba.pg_iou[l] ||
+                ba.pg_reg[l] < 5 * fa.lv.A || ba.pg_reg[l] - 5 * fa.lv.A > 64)
+                return IA_E_ARG;
             ba.g_pad[l] = (int32_t)(ba.pg_reg[l] - 5 * fa.lv.A);
+        }
     }
     fa.sums = nullptr; fa.gin = grad_result; fa.res = result;
     fa.big_logits = 0;

@@ -233,24 +233,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (i < ND) reinterpret_cast<uint32_t *>(s_x)[i] = in ? pv[u] : 0u;
             }
         } else {
-            constexpr int NIT = (kStPR * kSbPitch + 255) / 256;           // 21 values per thread, all requested first
-            uint16_t pv[NIT];
+            // 21 values per thread, requested in rounds of 7 (all 21 in flight next to the 88 weight registers were
+            // 20 registers over the budget of 2 waves / SIMD: scratch spills in the odd-width variant)
+            constexpr int NIT = (kStPR * kSbPitch + 255) / 256, RND = 7;
+            static_assert(NIT % RND == 0, "rounds must tile the staging loop");
+#pragma unroll 1
+            for (int u0 = 0; u0 < NIT; u0 += RND) {
+                uint16_t pv[RND];
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                int i = tid + 256 * u;
-                i = i < kStPR * kSbPitch ? i : kStPR * kSbPitch - 1;
-                const int pr = i / kSbPitch, e = i - pr * kSbPitch;
-                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-                const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
-                pv[u] = xb[(size_t)yc * row_f + xc];                      // clamped, unconditional
-            }
+                for (int u = 0; u < RND; ++u) {
+                    int i = tid + 256 * (u0 + u);
+                    i = i < kStPR * kSbPitch ? i : kStPR * kSbPitch - 1;
+                    const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+                    const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+                    const int yc = yi < 0 ? 0 : (yi >= a.H ? a.H - 1 : yi), xc = xe < 0 ? 0 : (xe >= row_f ? row_f - 1 : xe);
+                    pv[u] = xb[(size_t)yc * row_f + xc];                      // clamped, unconditional
+                }
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int i = tid + 256 * u;
-                const int pr = i / kSbPitch, e = i - pr * kSbPitch;
-                const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
-                const bool in = e < kStPCF + 1 && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
-                if (i < kStPR * kSbPitch) s_x[i] = in ? pv[u] : (uint16_t)0;
+                for (int u = 0; u < RND; ++u) {
+                    const int i = tid + 256 * (u0 + u);
+                    const int pr = i / kSbPitch, e = i - pr * kSbPitch;
+                    const int yi = 2 * r0 - 3 + pr, xe = e0 + e;
+                    const bool in = e < kStPCF + 1 && yi >= 0 && yi < a.H && xe >= 0 && xe < row_f;
+                    if (i < kStPR * kSbPitch) s_x[i] = in ? pv[u] : (uint16_t)0;
+                }
             }
         }
         __syncthreads();

@@ -52,7 +52,8 @@ class HeadTargets(C.Structure):
 class HeadLossCfg(C.Structure):
     _fields_ = [('gamma', C.c_float), ('alpha', C.c_float), ('loss_weight_cls', C.c_float),
                 ('beta', C.c_float), ('loss_weight_bbox', C.c_float),
-                ('attach_iou_target', C.c_int32), ('exact_large_logits', C.c_int32)]
+                ('attach_iou_target', C.c_int32), ('exact_large_logits', C.c_int32),
+                ('grad_rows_start_at_reg', C.c_int32)]
 
 
 class ImageDesc(C.Structure):

@@ -49,35 +49,54 @@ def _fold_bn(bn):
 def _stamp_slots(module):
     """where the tensors of `_stamp` live: (parameter / buffer dict, key) pairs -- a dict lookup per
     forward instead of a walk over the submodules through nn.Module.__getattr__ (32 us per fused module
-    and forward: a third of a batch-1 step's host time, which is what bounds that step)"""
-    slots = []
+    and forward: a third of a batch-1 step's host time, which is what bounds that step) -- and where the
+    modules that own them hang: (parent's `_modules` dict, name, module) triples, so that a submodule
+    REPLACED after fuse_inference (`blk.conv2 = other_conv`) is noticed (the slots alone kept
+    pointing into the old module's dicts and the stale folded weights were used silently)."""
+    slots, links = [], []
     # a ResNet's own folded copies derive from its stem only (the blocks below are fused modules
     # with their own stamps): do not re-fold the frozen stem because a trainable stage took an
     # optimizer step
-    scope = (module.conv1, module.norm1) if isinstance(module, ResNet) else (module,)
-    for m in (sub for top in scope for sub in top.modules()):
-        if isinstance(m, torch.nn.Conv2d):
-            slots.append((m._parameters, 'weight'))
-            if m.bias is not None:
-                slots.append((m._parameters, 'bias'))
-        elif isinstance(m, _BatchNorm) and m.running_var is not None:
-            slots.append((m._buffers, 'running_var'))
-            if m.weight is not None:
+    tops = ('conv1', module.norm1_name) if isinstance(module, ResNet) else (None,)
+    for top_name in tops:
+        top = module if top_name is None else module._modules[top_name]
+        if top_name is not None:
+            links.append((module._modules, top_name, top))
+        stack = [top]
+        while stack:
+            m = stack.pop()
+            for name, child in m._modules.items():
+                if child is not None:
+                    links.append((m._modules, name, child))
+                    stack.append(child)
+            if isinstance(m, torch.nn.Conv2d):
                 slots.append((m._parameters, 'weight'))
-    return slots
+                if m.bias is not None:
+                    slots.append((m._parameters, 'bias'))
+            elif isinstance(m, _BatchNorm) and m.running_var is not None:
+                slots.append((m._buffers, 'running_var'))
+                if m.weight is not None:
+                    slots.append((m._parameters, 'weight'))
+    return slots, links
 
 
 def _stamp(module):
     """identity + version of what the folded copies were derived from: every convolution weight
     and one running statistic per BatchNorm under `module`.  An optimizer step, a checkpoint
     load (in-place copies bump `_version`) or `.to(device / dtype)` (new storage, also a new buffer
-    object: the slots are looked up in the modules' own dicts every time) changes it.  The module
-    structure itself is fixed once fused (fuse_inference / unfuse_inference rebuild the slots)."""
-    slots = module.__dict__.get('_ia_stamp_slots')
-    if slots is None:
-        slots = module.__dict__['_ia_stamp_slots'] = _stamp_slots(module)
+    object: the slots are looked up in the modules' own dicts every time) changes it.  A submodule
+    that was replaced (or removed) since the slots were collected rebuilds them: the stamp then differs
+    from the stored one because the new module's tensors are other tensors."""
+    cached = module.__dict__.get('_ia_stamp_slots')
+    if cached is not None:
+        for d, name, child in cached[1]:
+            if d.get(name) is not child:
+                cached = None
+                break
+    if cached is None:
+        cached = module.__dict__['_ia_stamp_slots'] = _stamp_slots(module)
     out = []
-    for d, k in slots:
+    for d, k in cached[0]:
         t = d[k]
         out.append((t.data_ptr(), t._version) if t is not None else (0, 0))
     return tuple(out)

@@ -67,19 +67,32 @@ class CrossEntropyLoss(nn.Module):
             raise NotImplementedError('mask cross entropy belongs to the mask heads (out of scope)')
         self.use_sigmoid, self.use_mask, self.loss_weight = use_sigmoid, use_mask, loss_weight
 
+    def forward_level(self, cls_score, labels, label_weights, num_anchors, avg_factor):
+        """what AnchorHead.loss_single calls for a non-fused loss: cls_score (B, A*Cin, H, W), labels /
+        label_weights (B, N_l) -> the reference's flattened rows, cls_score.permute(0, 2, 3, 1).reshape(-1, Cin)
+        (anchor_head.py:150-160), then `forward` (the method was missing -- AttributeError on the
+        first training step of a CrossEntropyLoss head)"""
+        cin = cls_score.shape[1] // num_anchors
+        rows = cls_score.permute(0, 2, 3, 1).reshape(-1, cin)
+        return self.forward(rows, labels.reshape(-1), label_weights.reshape(-1), avg_factor=avg_factor)
+
     def forward(self, cls_score, label, label_weight, avg_factor=None, **kwargs):
         import torch.nn.functional as F
-        if avg_factor is None:
-            avg_factor = max(float((label_weight > 0).sum().item()), 1.0)
         if self.use_sigmoid:
             if cls_score.dim() != label.dim():            # integer labels 0..C -> one-hot over C columns
                 hot = torch.zeros_like(cls_score)
                 fg = torch.nonzero(label >= 1).flatten()
                 hot[fg, label[fg] - 1] = 1.0
                 label, label_weight = hot, label_weight.reshape(-1, 1).expand_as(cls_score)
+            # the default normaliser counts the EXPANDED (N, C) weights, like weighted_binary_cross_entropy
+            # (core/loss/losses.py:142-145: expansion first) -- ADVICE r5
+            if avg_factor is None:
+                avg_factor = max(float((label_weight > 0).sum().item()), 1.0)
             total = F.binary_cross_entropy_with_logits(cls_score, label.to(cls_score.dtype),
                                                        label_weight.to(cls_score.dtype), reduction='sum')
         else:
+            if avg_factor is None:
+                avg_factor = max(float((label_weight > 0).sum().item()), 1.0)
             total = (F.cross_entropy(cls_score, label, reduction='none') * label_weight).sum()
         return self.loss_weight * total.reshape(1) / avg_factor
 

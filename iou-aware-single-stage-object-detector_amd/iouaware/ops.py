@@ -1612,13 +1612,16 @@ class _HeadLossNhwcFn(torch.autograd.Function):
         if ctx.fused:
             # one gradient tensor per level shaped like the wider tensor; channels beyond reg | iou
             # (alignment padding) get zero gradient
-            # (the backward kernel writes the zero gradient of those channels itself when, as here, the
-            # iou slice follows the reg slice in the pixel row: ia_head_loss_bwd_nhwc)
+            # (_shared_base guarantees reg = channels [0, 4A), iou right behind: with that STATED in the cfg the
+            # backward kernel writes the zero gradient of the padding channels itself, ia_head_loss_bwd_nhwc;
+            # rows with more than 64 padding channels are cleared here and the flag stays off)
             g_base = [torch.empty(b.shape, dtype=torch.float32, device=dev, memory_format=cl)
                       for b in bases]
-            for l, b in enumerate(bases):
-                if b.shape[1] - (reg[l].shape[1] + iou[l].shape[1]) > 64:
-                    g_base[l].zero_()
+            in_kernel = all(b.shape[1] - (reg[l].shape[1] + iou[l].shape[1]) <= 64 for l, b in enumerate(bases))
+            ctx.cfg.grad_rows_start_at_reg = 1 if in_kernel else 0
+            if not in_kernel:
+                for gb in g_base:
+                    gb.zero_()
             for l in range(L):
                 gp.reg[l] = g_base[l].data_ptr() + (reg[l].data_ptr() - bases[l].data_ptr())
                 gp.iou[l] = g_base[l].data_ptr() + (iou[l].data_ptr() - bases[l].data_ptr())
@@ -1631,6 +1634,7 @@ class _HeadLossNhwcFn(torch.autograd.Function):
                 gp.reg[l], gp.iou[l] = g_reg[l].data_ptr(), g_iou[l].data_ptr()
                 gst.reg[l], gst.iou[l] = reg[l].shape[1], iou[l].shape[1]
             tail = g_reg + g_iou
+            ctx.cfg.grad_rows_start_at_reg = 0
         for l in range(L):
             gp.cls[l], gst.cls[l] = g_cls[l].data_ptr(), cls[l].shape[1]
         _lib.check(_lib.lib().ia_head_loss_bwd_nhwc(ctx.geom.ref(), C.byref(p), C.byref(st), ctx.B,
