@@ -301,6 +301,8 @@ class WinogradHead(object):
         cls, reg, iou = new(self.c_cls), new(self.c_reg), new(self.c_iou)
         # the 548 MB class logits are written FIRST: the (MFMA-bound) reg / iou GEMM behind them
         # gives their write-back time to drain before the row-max kernel streams them back in
+        # (round 6, measured again in bench steps, 2 x 20 steps each: class logits LAST -> decode stage 0.133 ms
+        # in-step against 0.120-0.121 this way; gpurun_out/r06_ab_clslast.txt)
         m_cls = batched_gemm(v[:36], self.u_cls, plan.buf('mc', (36, T, self.c_cls)))
         output_transform(plan, m_cls, self.c_cls, 1, self.b_cls, False, [(0, self.c_cls, cls, 0)])
         m_ri = batched_gemm(v[36:], self.u_ri, plan.buf('mr', (36, T, self.n_ri_pad)))
