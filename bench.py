@@ -131,6 +131,7 @@ class Stepper(object):
     back-to-back figures of decode_stage_roofline() stay beside it."""
     events, ev_next = (), 0                  # (class defaults: subclasses with their own __init__)
     pending = results = None
+    host_exchange, local_last = False, None
 
     def __init__(self, model, imgs, world):
         self.model, self.imgs, self.world = model, imgs, world
@@ -143,6 +144,31 @@ class Stepper(object):
         # (one pinned record, ~19 KB) is enqueued behind its detections and COLLECTED while batch
         # i + 1 runs on the device; drain() collects the last one inside the timed region.
         self.pending, self.results, self.host_buf, self.flip = None, None, [None, None], 0
+        self.exchange_ms, self.exchange_ev = [], []
+
+    def exchange_record(self, steps):
+        """the all-gather of the last `steps` steps: mean / max duration (call after a device synchronisation)"""
+        ms = self.exchange_ms if self.host_exchange else [a.elapsed_time(b) for a, b in self.exchange_ev]
+        ms = ms[-steps:]
+        if not ms:
+            return None
+        M = int(self.last[0].shape[1])
+        return {'collective': 'gloo all_gather_into_tensor of host records (rehearsal)' if self.host_exchange else
+                              'RCCL all_gather_into_tensor on the step\'s stream (HIP events around it)',
+                'ms_mean': round(sum(ms) / len(ms), 4), 'ms_max': round(max(ms), 4), 'steps': len(ms),
+                'bytes_per_rank': int(self.imgs.shape[0]) * (M * 6 + 1) * 4}
+
+    def interleave_matches_part_list(self):
+        """the gathered records of the last step against the reference's collect_results (tools/test.py:95-99):
+        part_list = every rank's results in rank order; ordered = [res for tup in zip(*part_list) for res in tup]"""
+        mine = [t.cpu().numpy() for t in self.local_last]
+        part_list = [None] * self.world
+        dist.all_gather_object(part_list, [tuple(a[i] for a in mine) for i in range(mine[0].shape[0])])
+        ordered = [res for tup in zip(*part_list) for res in tup]
+        got = [t.cpu().numpy() for t in self.last[:3]]
+        return len(ordered) == got[0].shape[0] and all(
+            np.array_equal(got[0][i], d) and np.array_equal(got[1][i], l) and int(got[2][i]) == int(n)
+            for i, (d, l, n) in enumerate(ordered))
 
     def submit_results(self, dets, labels, num):
         from iouaware.detectors import PendingResults
@@ -190,7 +216,21 @@ class Stepper(object):
         dets, labels, num, cls, reg, iou = self.local_detections(timed)
         nxt = self.submit_results(dets, labels, num) if dets.is_cuda else None
         if self.world > 1:
-            dets, labels, num = idist.all_gather_detections(dets, labels, num)
+            self.local_last = (dets, labels, num)
+            if self.host_exchange or not dets.is_cuda:
+                # --rehearsal (gloo): the records travel as host tensors; the copy waits for this rank's
+                # detections, the exchange proper is timed behind it
+                local = [t.cpu() for t in (dets, labels, num)]
+                t0 = time.perf_counter()
+                dets, labels, num = idist.all_gather_detections(*local)
+                self.__dict__.setdefault('exchange_ms', []).append((time.perf_counter() - t0) * 1e3)
+            else:
+                # RCCL all-gather on the step's stream, between two events (read after the timed region)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                dets, labels, num = idist.all_gather_detections(dets, labels, num)
+                ev[1].record()
+                self.__dict__.setdefault('exchange_ev', []).append(ev)
         if self.pending is not None:
             self.results = self.pending.collect()          # the previous batch: host work under this batch's device work
         self.pending = nxt
@@ -546,7 +586,7 @@ def wino_roofline(stepper, steps=2):
                      % steps)
 
 
-def timed_region(step, steps, warmup, world, sync, barrier, device, drain=None):
+def timed_region(step, steps, warmup, world, sync, barrier, device, drain=None, info=None):
     """the driver's timing contract: W untimed warm-up steps, then EXACTLY K steps between
     barrier + device synchronisation on both sides; the MAX over ranks of the elapsed time.
     drain: finishes whatever the last step left in flight on the host side (the last batch's
@@ -564,10 +604,15 @@ def timed_region(step, steps, warmup, world, sync, barrier, device, drain=None):
         step()
     if drain is not None:
         drain()
+    if info is not None:
+        sync()
+        info['local_busy_s'] = time.perf_counter() - t0    # this rank's steps done (before it waits for the others)
     if world > 1:
         barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    if info is not None:
+        info['local_elapsed_s'] = elapsed                  # this rank's own clock (the line reports every rank's)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -959,6 +1004,11 @@ def main():
     ap.add_argument('--nchw', action='store_true', help='run the convolutions in NCHW')
     ap.add_argument('--no-winograd', action='store_true',
                     help='head 3x3 convolutions through MIOpen instead of the Winograd path')
+    ap.add_argument('--rehearsal', action='store_true',
+                    help='N > 1 without N GPUs: every rank drives GPU 0 (oversubscribed), process group on '
+                         'gloo, records exchanged as host tensors -- launcher, pinning, the real step, the '
+                         'all-gather, its rank interleave and the per-rank / exchange fields of the line, i.e. '
+                         'everything of `--gpus 8` except RCCL itself.  Not a scaling measurement.')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU: fake detections on CPU, gloo backend -- launcher, process group, '
                          'timed region and result exchange only')
@@ -974,7 +1024,7 @@ def main():
                                  'external launcher' if launched else 'single process')
     if not launched and (args.gpus or 1) > 1:
         # `python bench.py --gpus N` without a launcher: start the N ranks here
-        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        if not args.dry_run and not args.rehearsal and torch.cuda.device_count() < args.gpus:
             raise SystemExit('bench.py --gpus %d: this node shows %d GPU(s)'
                              % (args.gpus, torch.cuda.device_count()))
         raise SystemExit(launch(args.gpus, sys.argv[1:]))
@@ -989,24 +1039,28 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-        torch.cuda.set_device(local_rank)
-        device = torch.device('cuda', local_rank)
+        dev_index = 0 if args.rehearsal else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device('cuda', dev_index)
+    host_group = args.dry_run or args.rehearsal            # gloo: collectives on host tensors
     rccl_ranks, rank_devices = 1, None
     # every rank on the cores of its GPU's NUMA node, a disjoint share each (no-op for one rank)
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    affinity = idist.pin_rank(local_rank, local_world, device_count=0 if args.dry_run else None)
+    affinity = idist.pin_rank(local_rank, local_world, device_count=0 if args.dry_run else None,
+                               same_device=args.rehearsal)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo' if args.dry_run else 'nccl')
+        dist.init_process_group(backend='gloo' if host_group else 'nccl')
         if dist.get_world_size() != world:
             raise SystemExit('process group of %d ranks, launcher said %d'
                              % (dist.get_world_size(), world))
-        rccl_ranks, rank_devices = group_ranks(device)
-        if rccl_ranks != world or (not args.dry_run and len(rank_devices) != world):
+        rccl_ranks, rank_devices = group_ranks(torch.device('cpu') if args.rehearsal else device)
+        if rccl_ranks != world or (not host_group and len(rank_devices) != world):
             raise SystemExit('collective sees %d ranks on devices %s, expected %d distinct'
                              % (rccl_ranks, rank_devices, world))
     sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
-    barrier = dist.barrier if args.dry_run else (lambda: dist.barrier(device_ids=[local_rank]))
+    barrier = dist.barrier if host_group else (lambda: dist.barrier(device_ids=[local_rank]))
+    reduce_device = torch.device('cpu') if args.rehearsal else device
 
     if args.dry_run:
         stepper = DryRunStepper(rank, world)
@@ -1056,15 +1110,27 @@ def main():
     if not args.nchw:
         imgs = imgs.contiguous(memory_format=torch.channels_last)
     stepper = Stepper(model, imgs, world)
+    stepper.host_exchange = bool(args.rehearsal)
 
     def step():
         stepper.step(timed=True)
 
     if rank == 0:
         stepper.stage_events(args.steps, skip=args.warmup)
-    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, device, drain=stepper.drain)
+    info = {}
+    elapsed = timed_region(step, args.steps, args.warmup, world, sync, barrier, reduce_device, drain=stepper.drain,
+                           info=info)
     in_step = stepper.stage_times_ms() if rank == 0 else []
     host_results = stepper.results
+    multi = None
+    if world > 1:
+        # what a scaling run is read by: every rank's own clock, the exchange step, the rank interleave
+        clocks = [None] * world
+        dist.all_gather_object(clocks, (rank, info['local_busy_s'], info['local_elapsed_s']))
+        multi = {'per_rank_img_s': [round(batch * args.steps / c[1], 2) for c in sorted(clocks)],
+                 'per_rank_busy_s': [round(c[1], 4) for c in sorted(clocks)],
+                 'exchange': stepper.exchange_record(args.steps),
+                 'interleave_equals_zip_part_list': bool(stepper.interleave_matches_part_list())}
 
     wino = wino_roofline(stepper) if rank == 0 and dtype == torch.float32 else None
     if rank == 0:
@@ -1084,8 +1150,11 @@ def main():
         out = {
             'metric': 'images/sec at 1333x800, IoU-aware RetinaNet R-50-FPN' if headline else
                       'images/sec at 1333x800, IoU-aware RetinaNet (%s)' % args.config,
-            'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': world,
-            'rccl_ranks': rccl_ranks, 'rank_devices': rank_devices,
+            'value': round(n_img / elapsed, 3), 'unit': 'img/s', 'n_gpus': 1 if args.rehearsal else world,
+            'rccl_ranks': 0 if args.rehearsal else rccl_ranks, 'rank_devices': rank_devices,
+            'ranks': world, 'multi_rank': multi,
+            'rehearsal': ('%d ranks oversubscribing ONE MI355X, process group on gloo, records exchanged as host '
+                          'tensors: the N > 1 code path, NOT a scaling measurement' % world) if args.rehearsal else None,
             'launched_by': launched_by, 'affinity_rank0': affinity,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -1187,7 +1256,7 @@ def main():
             out['other_configs'] = None
         print(json.dumps(out))
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -103,13 +103,14 @@ def rank_cpu_plan(local_rank, local_world, numa_nodes, allowed, sysfs='/sys'):
                                                                        k + 1, len(peers))
 
 
-def pin_rank(local_rank, local_world, device_count=None, sysfs='/sys', apply=True):
+def pin_rank(local_rank, local_world, device_count=None, sysfs='/sys', apply=True, same_device=False):
     """Bind this process (and the threads it starts later) to the cores of the NUMA node its GPU
     hangs off, a disjoint share per rank, and size the host thread pools to it.  One Python feeder per
     GPU issues ~140 launches per 20 ms step; eight unpinned feeders on a two-socket host migrate
     between sockets and share cores with each other's helper threads.  The
     reference leaves placement to the launcher (tools/dist_test.sh:9-10).  -> record for the
-    benchmark line; never raises (an unreadable topology leaves the affinity alone)."""
+    benchmark line; never raises (an unreadable topology leaves the affinity alone).
+    same_device: every rank drives device 0 (bench.py --rehearsal): the ranks share that GPU's NUMA node."""
     rec = {'local_rank': int(local_rank), 'pinned': False}
     try:
         allowed = os.sched_getaffinity(0)
@@ -117,8 +118,9 @@ def pin_rank(local_rank, local_world, device_count=None, sysfs='/sys', apply=Tru
         n = device_count if device_count is not None else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
         for r in range(local_world):
             bus = None
-            if r < n:
-                pr = torch.cuda.get_device_properties(r)
+            d = 0 if same_device else r
+            if d < n:
+                pr = torch.cuda.get_device_properties(d)
                 if hasattr(pr, 'pci_bus_id'):
                     bus = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id,
                                                 getattr(pr, 'pci_device_id', 0))

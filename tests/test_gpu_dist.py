@@ -2,6 +2,7 @@
 one-GPU box allows: a one-rank process group, the collective forced -- RCCL accepts the record
 buffer's shape / dtype, the interleave and unpacking are right on device tensors.  World sizes
 > 1 are covered on CPU with gloo (tests/test_dist_gloo.py); N > 1 on hardware is the driver's."""
+import json
 import os
 import socket
 
@@ -174,6 +175,40 @@ def test_fused_launch_on_a_quarter_of_the_chip():
     if os.path.isdir(out):
         with open(os.path.join(out, 'oversubscription_report.txt'), 'a') as fh:
             fh.write('2 ranks, HSA_CU_MASK=0:0-63: %s\\n' % recs)
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_8_rehearsal_on_one_gpu():
+    """`bench.py --gpus 8` itself -- its launcher (torch.distributed.run, 8 ranks), the per-rank
+    core pinning, the real step (network + post-conv path, batch 8 per rank), the all-gather of the records and the
+    rank interleave -- with the 8 ranks oversubscribing the ONE GPU of this box (--rehearsal: gloo, host records;
+    RCCL refuses two ranks on a device).  The gathered records of the last step equal the reference's
+    `[res for tup in zip(*part_list) for res in tup]` (tools/test.py:95-99), and the line carries what a scaling
+    run is read by: every rank's own img/s, the exchange time, the number of ranks."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), '..')
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--rehearsal', '--steps', '3',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-live-pmc', '--no-train', '--no-pipeline',
+                        '--no-other-configs'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert p.returncode == 0 and lines, p.stderr.decode()[-3000:]
+    rec = json.loads(lines[-1])
+    assert rec['ranks'] == 8 and rec['n_gpus'] == 1 and rec['rehearsal']
+    assert rec['launched_by'].startswith('bench.py --gpus 8')
+    m = rec['multi_rank']
+    assert m['interleave_equals_zip_part_list'] is True
+    assert len(m['per_rank_img_s']) == 8 and all(v > 0 for v in m['per_rank_img_s'])
+    assert m['exchange']['steps'] == 3 and m['exchange']['ms_mean'] > 0
+    assert m['exchange']['bytes_per_rank'] == 8 * 601 * 4          # 8 images x (100 x 6 + 1) words
+    assert rec['config']['global_batch'] == 64 and rec['config']['parallelism'] == 'dp8'
+    out = os.path.join(root, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'rehearsal_gpus8.json'), 'w') as fh:
+            fh.write(lines[-1] + '\n')
 
 
 def test_pin_rank_reads_the_real_topology():
