@@ -139,6 +139,24 @@ def gen_nms_f64():
         out['edge_thr_%d' % j] = np.float32(thr)
     out['edge_dets'] = d
     assert out['edge_keep_0_float64'].tolist() == [0, 1] and out['edge_keep_0_float32'].tolist() == [0]
+    # the threshold arrives as a C float (nms_cpu.cpp:5 `const float threshold`) and is compared in
+    # scalar_t: exactly representable thresholds (0.5, 0.25) against IoUs that hit them exactly --
+    # both instantiations suppress --, and 0.3 (not representable: float(0.3) = 0.30000001192...)
+    # against an IoU of 0.300000005: above 0.3, below float(0.3) -- the double instantiation keeps
+    # the box, the float one (where the width rounds to 3 and 30 / 100 rounds up to float(0.3))
+    # suppresses it.  A port that compares against double(0.3) gets the first of them wrong.
+    e2 = [(np.array([[0, 0, 9, 9, 0.9], [0, 0, 4, 9, 0.8]], np.float64), 0.5),            # IoU = 50 / 100
+          (np.array([[0, 0, 9, 9, 0.9], [0, 0, 4, 4, 0.8]], np.float64), 0.25),           # IoU = 25 / 100
+          (np.array([[0, 0, 9, 9, 0.9], [0, 0, 2.00000005, 9, 0.8]], np.float64), 0.3)]   # IoU = 0.300000005
+    for j, (dd, thr) in enumerate(e2):
+        for dt in (np.float64, np.float32):
+            _, inds = nw.nms(torch.from_numpy(dd.astype(dt)), float(np.float32(thr)))
+            out['edge2_keep_%d_%s' % (j, np.dtype(dt).name)] = inds.numpy()
+        out['edge2_dets_%d' % j] = dd
+        out['edge2_thr_%d' % j] = np.float32(thr)
+    assert out['edge2_keep_0_float64'].tolist() == [0] and out['edge2_keep_0_float32'].tolist() == [0]
+    assert out['edge2_keep_1_float64'].tolist() == [0] and out['edge2_keep_1_float32'].tolist() == [0]
+    assert out['edge2_keep_2_float64'].tolist() == [0, 1] and out['edge2_keep_2_float32'].tolist() == [0]
     out['num_cases'] = len(cases)
     print('nms_f64: kept', [len(out['keep_%d' % i]) for i in range(len(cases))],
           'edge', {k: v.tolist() for k, v in out.items() if k.startswith('edge_keep')})

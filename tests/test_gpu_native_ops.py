@@ -53,6 +53,15 @@ def test_nms_float64_matches_the_reference_op(golden_dir):
         for dt in (np.float64, np.float32):
             _, inds = nms_op.nms(torch.from_numpy(d.astype(dt)).cuda(), thr)
             assert np.array_equal(inds.cpu().numpy(), f['edge_keep_%d_%s' % (j, np.dtype(dt).name)]), (j, dt)
+    # thresholds that are / are not exactly representable as a C float (nms_cpu.cpp:5): IoU exactly 0.5
+    # and 0.25 against 0.5 / 0.25 (both types suppress); IoU 0.300000005 against float(0.3) =
+    # 0.30000001192...: the double op keeps the box (a port comparing with double(0.3) would not)
+    for j in range(3):
+        dd, thr = f['edge2_dets_%d' % j], float(f['edge2_thr_%d' % j])
+        for dt in (np.float64, np.float32):
+            _, inds = nms_op.nms(torch.from_numpy(dd.astype(dt)).cuda(), thr)
+            assert np.array_equal(inds.cpu().numpy(), f['edge2_keep_%d_%s' % (j, np.dtype(dt).name)]), (j, dt)
+    assert f['edge2_keep_2_float64'].tolist() == [0, 1] and f['edge2_keep_2_float32'].tolist() == [0]
     # IoU exactly 1/3 against float(1/3): the two instantiations of the reference disagree, so do ours
     assert f['edge_keep_0_float64'].tolist() == [0, 1] and f['edge_keep_0_float32'].tolist() == [0]
     # ties in the scores: canonical order (index ascending), same bits twice

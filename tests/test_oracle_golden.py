@@ -79,6 +79,11 @@ def test_nms_cases(oracle_lib, golden_dir):
     assert oracle_lib.nms(n['edge_dets_0'], float(n['edge_thr_0'])).tolist() == [0]
     assert oracle_lib.nms(n['edge_dets_1'], float(n['edge_thr_1'])).tolist() == [0, 1]
     assert np.array_equal(n['edge_keep_0'], [0]) and np.array_equal(n['edge_keep_1'], [0, 1])
+    # the fp32 instantiation on the threshold-representability cases of nms_f64.npz
+    f = np.load(os.path.join(golden_dir, 'nms_f64.npz'))
+    for j in range(3):
+        keep = oracle_lib.nms(f['edge2_dets_%d' % j].astype(np.float32), float(f['edge2_thr_%d' % j]))
+        assert np.array_equal(keep, f['edge2_keep_%d_float32' % j]), j
 
 
 def test_nms_matches_real_reference_binary(oracle_lib):
