@@ -78,6 +78,12 @@ class ImageTransform(object):
         for b, im in enumerate(dev_imgs):
             h, w = int(im.shape[0]), int(im.shape[1])
             nh, nw, sf = rescale_size(h, w, scale, keep_ratio)
+            if nh < 1 or nw < 1:
+                # e.g. an 842 x 1 image under keep_ratio: int(1 * 0.27 + 0.5) = 0 columns.  The reference
+                # fails here as well (mmcv.imrescale -> cv2.resize asserts a non-empty dsize,
+                # transforms.py:35); a named error instead of the C-ABI's IA_E_ARG
+                raise ValueError('image %d: %d x %d rescaled to an empty %d x %d image (scale %s, keep_ratio=%s)'
+                                 % (b, h, w, nh, nw, scale, keep_ratio))
             ph, pw = self._pad(nh, nw)
             PH, PW = max(PH, ph), max(PW, pw)
             descs[b] = _lib.ImageDesc(im.data_ptr(), h, w, nh, nw, int(bool(flips[b])))

@@ -338,6 +338,9 @@ def image_transform(img, scale, flip=False, keep_ratio=True, mean=(0, 0, 0), std
     -> (img (3,ph,pw) fp32, img_shape, pad_shape, scale_factor)"""
     h, w = img.shape[:2]
     nh, nw, sf = rescale_size(h, w, scale, keep_ratio)
+    if nh < 1 or nw < 1:
+        # cv2.resize (behind mmcv.imrescale, transforms.py:35) asserts a non-empty dsize: the reference raises
+        raise ValueError('rescaled size %d x %d is empty' % (nh, nw))
     r = resize_bilinear_u8(img, nh, nw)
     if size_divisor is not None:
         ph = int(np.ceil(nh / size_divisor)) * size_divisor

@@ -48,6 +48,17 @@ def test_image_transform_equals_oracle(oracle_lib, h, w, scale, keep):
             assert G.same_bits(got.cpu().numpy(), want), (h, w, flip, smooth)
 
 
+def test_an_empty_rescaled_image_is_a_named_error():
+    """the reference fails on such an input as well (cv2.resize asserts a non-empty dsize); the host side
+    names the image instead of passing a 0-wide destination to the C-ABI (IA_E_ARG)"""
+    from iouaware.preprocess import ImageTransform
+    tf = ImageTransform(size_divisor=32, **NORM)
+    with pytest.raises(ValueError, match='empty 227 x 0'):
+        tf(np.zeros((842, 1, 3), np.uint8), (172, 227), False, True)
+    with pytest.raises(ValueError, match='image 1'):
+        tf.batch([np.zeros((64, 64, 3), np.uint8), np.zeros((842, 1, 3), np.uint8)], (172, 227))
+
+
 def test_batch_mixed_sizes_and_channels_last(oracle_lib):
     from iouaware.preprocess import ImageTransform
     rs = np.random.RandomState(3)

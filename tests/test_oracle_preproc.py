@@ -31,6 +31,16 @@ def test_sizes_follow_mmcv(oracle_lib):
     assert np.array_equal(sf, np.array([1.6, 1.6, 1.6, 1.6], np.float32))
 
 
+def test_an_empty_rescaled_image_is_rejected(oracle_lib):
+    """842 x 1 under keep_ratio: int(1 * 227 / 842 + 0.5) = 0 columns -- cv2.resize behind mmcv.imrescale
+    (transforms.py:35) asserts a non-empty dsize, so the reference raises; found by tools/fuzz_preproc_soft.py
+    seed 605084 (the oracle used to return a 227 x 0 image, the C-ABI answered IA_E_ARG)"""
+    import pytest
+    assert oracle_lib.rescale_size(842, 1, (172, 227))[:2] == (227, 0)
+    with pytest.raises(ValueError, match='empty'):
+        oracle_lib.image_transform(np.zeros((842, 1, 3), np.uint8), (172, 227), False, True, size_divisor=32)
+
+
 def test_resize_close_to_exact_bilinear_and_special_cases(oracle_lib):
     rs = np.random.RandomState(0)
     for (h, w, nh, nw) in [(480, 640, 800, 1067), (600, 900, 200, 300), (33, 47, 567, 800),

@@ -35,7 +35,14 @@ def preproc_case(seed):
     tag = 'seed %d preproc %dx%d -> scale %s keep=%d flip=%d divisor=%d' % (seed, h, w, scale, keep, flip, div)
     img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
     tf = ImageTransform(size_divisor=div, **NORM)
-    want, ishape, pshape, sf = oracle.image_transform(img, scale, flip, keep, size_divisor=div, **NORM)
+    try:
+        want, ishape, pshape, sf = oracle.image_transform(img, scale, flip, keep, size_divisor=div, **NORM)
+    except ValueError as e:                      # an empty rescaled image: the reference (cv2.resize) raises too
+        try:
+            tf(img, scale, flip, keep)
+        except ValueError:
+            return tag + '  (both reject: %s)' % e
+        raise AssertionError(tag + ': the oracle rejects (%s), the HIP path does not' % e)
     got, gi, gp, gsf = tf(img, scale, flip, keep)
     assert tuple(gi) == tuple(ishape) and tuple(gp) == tuple(pshape), tag + ' shapes %s %s vs %s %s' % (gi, gp, ishape, pshape)
     assert np.array_equal(np.asarray(gsf, np.float64), np.asarray(sf, np.float64)), tag + ' scale factor'
