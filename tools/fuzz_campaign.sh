@@ -18,12 +18,12 @@ run() {
   tail -2 $OUT/last.log | cut -c1-220 | sed 's/^/     /' >> $REP
   if [ $rc -ne 0 ] || [ $n_bad -ne 0 ]; then cp $OUT/last.log $OUT/failed_$1.log; fi
 }
-run fuzz_get_bboxes.py 400 $((BASE + 0))
-run fuzz_nms_ops.py 500 $((BASE + 1000))
-run fuzz_fused_model.py 80 $((BASE + 2000))
-run fuzz_detector.py 80 $((BASE + 3000))
-run fuzz_losses.py 200 $((BASE + 4000))
-run fuzz_preproc_soft.py 300 $((BASE + 5000))
-run fuzz_targets.py 300 $((BASE + 6000))
-run fuzz_train.py 30 $((BASE + 7000))
+run fuzz_get_bboxes.py ${N_GB:-400} $((BASE + 0))
+run fuzz_nms_ops.py ${N_NMS:-500} $((BASE + 1000))
+run fuzz_fused_model.py ${N_FM:-80} $((BASE + 2000))
+run fuzz_detector.py ${N_DET:-80} $((BASE + 3000))
+run fuzz_losses.py ${N_LOSS:-200} $((BASE + 4000))
+run fuzz_preproc_soft.py ${N_PRE:-300} $((BASE + 5000))
+run fuzz_targets.py ${N_TGT:-300} $((BASE + 6000))
+run fuzz_train.py ${N_TR:-30} $((BASE + 7000))
 cat $REP
